@@ -1,0 +1,35 @@
+# Builds the MI355X (gfx950) Gibbs library and the CPU parity oracle.
+#   make            -> grample_amd/libgrample_hip.so + oracle/liboracle.so
+# hipcc cross-compiles for gfx950 without a GPU present.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH ?= gfx950
+CSRC := grample_amd/csrc
+OBJDIR := build/obj
+# -ffp-contract=off: the conditional-threshold arithmetic is shared by the
+# sweep kernel, the memoisation kernel and the probe; it must round the same
+# way in all three.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-result
+LIB := grample_amd/libgrample_hip.so
+OBJS := $(OBJDIR)/kernels.o $(OBJDIR)/sampler.o $(OBJDIR)/host_model.o $(OBJDIR)/compiled_model.o
+
+all: $(LIB) oracle
+
+$(OBJDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/grample_hip.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+
+oracle:
+	$(MAKE) -s -C oracle liboracle.so
+
+clean:
+	rm -rf build $(LIB)
+	$(MAKE) -s -C oracle clean
+
+.PHONY: all oracle clean

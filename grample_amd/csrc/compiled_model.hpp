@@ -1,0 +1,60 @@
+// Device image of one chain group's model ("variant"): what NewGibbsSimple's
+// bookkeeping (gibbs-simple.go:68-82: log tables + varFuncs) becomes on the
+// GPU.  Everything the per-update code needs is laid out so that, with the
+// updated variable wave-uniform, all metadata comes through scalar loads and
+// the only per-lane traffic is chain state and table rows.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "host_model.hpp"
+
+namespace gr {
+
+// Per-variable "program" (uint32 words), direct path:
+//   [0] Card | rowlen << 8 | n_factors << 16
+//   [1] histogram offset of the variable (sum of Card of lower ids)
+//   per factor containing the variable, in Model.Funcs order:
+//     [.] offset (floats) of this (factor, variable) VIEW table inside the variant's view pool
+//     [.] n_others
+//     n_others x { other var id, stride (floats) }
+// A view table is the factor's log table re-laid with the updated variable's
+// value fastest: view[o * rowlen + val], o = mixed-radix index of the OTHER
+// scope variables in scope order.  rowlen = 2 for Card <= 2, else Card rounded
+// up to 4, so the Card candidate values are one aligned vector read.
+//
+// Memoised path, per variable:
+//   [0] Card | n_neighbours << 8
+//   [1] histogram offset
+//   [2] offset (words) of the variable's threshold table inside the variant's table pool
+//   n_neighbours x { neighbour var id, mixed-radix multiplier }
+// table[(cfg) * (Card-1) + i] = i-th cumulative threshold (u32) of the
+// conditional given blanket configuration cfg = sum mult * x_neighbour.
+struct VariantImage {
+    std::vector<uint32_t> prog;     // direct programs, all variables
+    std::vector<uint32_t> prog_off; // [n_vars] word offset of each variable's direct program
+    std::vector<float> views;       // view-table pool (f32 log potentials)
+    std::vector<uint32_t> free_vars;// selectable variables: FixedVal < 0 and not Collapsed (sampler.go:146-156)
+    bool cpt_ok = false;            // memoised path available
+    std::vector<uint32_t> cprog;    // memoised programs
+    std::vector<uint32_t> cprog_off;// [n_vars]
+    uint32_t cpt_words = 0;         // size of the threshold pool
+    uint32_t max_cfg = 0;           // largest blanket configuration count of any variable
+};
+
+struct CompileLimits {
+    uint32_t max_cpt_words = 28 * 1024; // threshold pool budget (words) for the memoised path
+    uint32_t max_cpt_neighbours = 16;
+};
+
+inline uint32_t RowLen(int card) { return card <= 2 ? 2u : (uint32_t)((card + 3) & ~3); }
+
+// `m` must be in log space (every Function.IsLog).  Throws gr::Error.
+VariantImage CompileVariant(const Model &m, const CompileLimits &lim);
+
+// var -> indices into m.Funcs containing it, in Funcs order (gibbs-simple.go:72-81)
+std::vector<std::vector<int>> VarFuncs(const Model &m);
+// varNeighbors (gibbs-collapsed.go:44-66): sorted ids of all vars sharing a factor with v, v included
+std::vector<std::vector<int>> VarNeighbors(const Model &m);
+
+} // namespace gr

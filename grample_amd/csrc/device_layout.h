@@ -1,0 +1,48 @@
+// Structures shared by the host launch code and the gfx950 kernels.
+#pragma once
+#include <stdint.h>
+
+namespace gr {
+
+// One per chain group; all offsets index the sampler-wide pools below.
+struct VariantDesc {
+    uint32_t prog_base;    // words, into progs
+    uint32_t progoff_base; // entries, into prog_off ([n_vars] per variant)
+    uint32_t views_base;   // floats, into views (multiple of 4)
+    uint32_t views_len;    // floats (multiple of 4)
+    uint32_t free_base;    // entries, into free_vars
+    uint32_t n_free;
+    uint32_t cprog_base;   // words, into cprogs
+    uint32_t cprogoff_base;// entries, into cprog_off
+    uint32_t cpt_base;     // words, into cpt
+    uint32_t cpt_len;      // words
+    uint32_t pad0, pad1;
+};
+
+struct SweepParams {
+    const VariantDesc *variants;
+    const uint32_t *progs;
+    const uint32_t *prog_off;
+    const float *views;
+    const uint32_t *free_vars;
+    const uint32_t *cprogs;
+    const uint32_t *cprog_off;
+    const uint32_t *cpt;
+    unsigned char *state;       // [n_vars][pitch] chain-minor: one coalesced 64-B line per wave per variable
+    unsigned long long *counts; // [n_variants][H]
+    uint32_t n_vars;
+    uint32_t H;                 // sum of Card
+    uint32_t n_chains;          // chains on this device
+    uint32_t pitch;             // row pitch of state (chains rounded up to 256)
+    uint32_t chains_per_variant;
+    uint32_t chain_offset_lo, chain_offset_hi; // global id of local chain 0 (multiple of 64)
+    uint32_t seed_lo, seed_hi;
+    uint32_t step0_lo, step0_hi; // first update index of this launch
+    uint32_t n_steps;           // updates per chain in this launch
+    uint32_t counting;          // 0 = burn-in (chain.go:166-172), 1 = oneSample(true)
+    uint32_t sequential;        // 1 = never co-issue commuting updates
+    uint32_t lds_hist_off;      // byte offsets inside dynamic LDS
+    uint32_t lds_tab_off;
+};
+
+} // namespace gr

@@ -1,0 +1,40 @@
+// Host-visible launchers of the gfx950 kernels in kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+
+namespace gr {
+
+struct CollapseArgs {
+    uint32_t n_entries;      // size of the new factor's table
+    uint32_t card_v;         // Card of the collapsed variable
+    uint32_t n_new;          // arity of the new factor
+    uint32_t n_fac;          // factors containing the variable
+    const uint32_t *new_card;   // [n_new]
+    const int32_t *new_fixed;   // [n_new] FixedVal of each new-factor variable
+    const uint32_t *fac_off;    // [n_fac+1] offsets into fac_pos / fac_stride
+    const int32_t *fac_pos;     // per factor scope position: index into the new factor's vars, or -1 = the collapsed variable
+    const uint32_t *fac_stride; // stride of that scope position in the factor's table
+    const uint32_t *fac_tab;    // [n_fac] offset of the factor's table in `tables`
+    const double *tables;       // f64 log tables of those factors
+    double *out_table;          // [n_entries] log space after the 1e-6 rule (function.go:126-142)
+    double *out_partial;        // [gridDim.x][card_v] block sums of p per value
+};
+
+constexpr int kMaxSupportedCard = 64; // largest Card the register-resident conditional handles
+
+hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, uint32_t blocks, uint32_t threads,
+                        uint32_t lds_bytes, hipStream_t s);
+hipError_t launch_init_state(unsigned char *state, const int32_t *card, const int32_t *fixed, uint32_t n_vars, uint32_t pitch,
+                             uint32_t chain_begin, uint32_t chain_end, uint64_t chain_offset, uint64_t seed, uint32_t epoch,
+                             hipStream_t s);
+hipError_t launch_build_cpt(const VariantDesc &vd, const uint32_t *progs, const uint32_t *prog_off, const float *views,
+                            const uint32_t *cprogs, const uint32_t *cprog_off, uint32_t *cpt, const int32_t *card,
+                            const int32_t *fixed, uint32_t n_vars, uint32_t max_cfg, int max_card, hipStream_t s);
+hipError_t launch_conditional(const VariantDesc &vd, const uint32_t *progs, const uint32_t *prog_off, const float *views,
+                              uint32_t v, const int32_t *state, double *probs, int max_card, hipStream_t s);
+hipError_t launch_collapse(const CollapseArgs &a, uint32_t blocks, hipStream_t s);
+
+} // namespace gr

@@ -1,0 +1,473 @@
+// gfx950 (MI355X / CDNA4) kernels of the Gibbs hot path.
+//
+// Execution shape: one chain per lane, 64 chains per wavefront.  Every lane of
+// a wavefront updates the SAME variable at each step (the scan sequence is a
+// per-wavefront Philox stream), so
+//   * all model metadata (which factors, which neighbours, strides, table
+//     offsets) is wave-uniform -> scalar loads + SALU, no VALU work;
+//   * chain state lives in LDS as state[var][lane] (one byte per variable and
+//     chain): every state access is a conflict-free 64-byte row;
+//   * table rows are per-lane LDS gathers with at most prod(Card of the other
+//     scope vars) distinct addresses per wave (broadcast on equal addresses);
+//   * the histogram update for binary variables is one ballot + popcount.
+// There is no MFMA here: this is gather / reduce work, not a contraction.
+//
+// Reference behaviour implemented (file:line in CraigKelly/grample):
+//   select variable      sampler/sampler.go:135-174  (UniformSampler.VarSample)
+//   gather + log-sum     sampler/gibbs-simple.go:175-220, model/function.go:146-202
+//   stabilise/exp/floor  sampler/gibbs-simple.go:227-258
+//   categorical draw     sampler/sampler.go:90-130   (WeightedSample)
+//   write back + count   sampler/gibbs-simple.go:267, sampler/chain.go:221-246
+//   start state          sampler/gibbs-simple.go:84-112
+//   collapse             sampler/gibbs-collapsed.go:206-272
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+#include "kernels.h"
+#include "philox.h"
+
+namespace gr {
+
+// ------------------------------------------------------------------ helpers
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+
+// Cumulative draw thresholds of the conditional given the C summed log
+// potentials w[] (gibbs-simple.go:227-258 + sampler.go:110-123).
+//   reference: shift so min(w) = 1.5 when min < -8, exp, tot = sum, then
+//   SEQUENTIALLY for i: if w_i/tot < 1e-6 { d = tot*1e-6; tot += d; w_i += d },
+//   then WeightedSample re-sums and picks the first i with r <= cum_i, r = U*tot.
+// here: shift by max(w) instead (identical after normalisation; keeps f32 exp in
+// range), f32 exp, everything after it in f64 like the reference.  The draw is
+// "value = #{ i : u >= T_i }" with u a 32-bit uniform and T_i = round(cum_i/tot * 2^32).
+template <int MAXC>
+__device__ __forceinline__ void thresholds(const float (&w)[MAXC], const int C, uint32_t (&T)[MAXC > 1 ? MAXC - 1 : 1]) {
+    float m = w[0];
+#pragma unroll
+    for (int i = 1; i < MAXC; ++i)
+        if (i < C) m = fmaxf(m, w[i]);
+    double d[MAXC];
+    double tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+        if (i < C) {
+            d[i] = (double)__expf(w[i] - m);
+            tot += d[i];
+        }
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+        if (i < C) {
+            if (d[i] < 1e-6 * tot) { // every value must stay possible (gibbs-simple.go:246-258)
+                const double delta = tot * 1e-6;
+                tot += delta;
+                d[i] += delta;
+            }
+        }
+    double tot2 = 0.0; // WeightedSample re-sums the weights (sampler.go:110-116)
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i)
+        if (i < C) tot2 += d[i];
+    const double scale = 4294967296.0 / tot2;
+    double cum = 0.0;
+#pragma unroll
+    for (int i = 0; i < MAXC - 1; ++i)
+        if (i < C - 1) {
+            cum += d[i];
+            const double t = fmin(rint(cum * scale), 4294967295.0);
+            T[i] = (uint32_t)t;
+        }
+}
+
+template <int MAXC>
+__device__ __forceinline__ uint32_t pick(const uint32_t (&T)[MAXC > 1 ? MAXC - 1 : 1], const int C, const uint32_t u) {
+    uint32_t val = 0;
+#pragma unroll
+    for (int i = 0; i < MAXC - 1; ++i)
+        if (i < C - 1) val += (u >= T[i]) ? 1u : 0u;
+    return val;
+}
+
+// Summed log potentials of variable `pg` (its direct program) for every
+// candidate value, reading neighbour values through `get(var)`.
+// `tab` = this variant's view-table pool (LDS or global).
+template <int MAXC, class Getter>
+__device__ __forceinline__ void log_weights(const uint32_t *__restrict__ pg, const float *tab, Getter get, float (&w)[MAXC],
+                                            const uint32_t p0, const uint32_t p1, const uint32_t p2, bool &conflict) {
+    const uint32_t h = pg[0];
+    const uint32_t rowlen = (h >> 8) & 0xffu;
+    const uint32_t nf = h >> 16;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) w[i] = 0.f;
+    const uint32_t *q = pg + 2;
+    for (uint32_t f = 0; f < nf; ++f) { // factors in Model.Funcs order (gibbs-simple.go:186)
+        uint32_t o = q[0];
+        const uint32_t no = q[1];
+        q += 2;
+        for (uint32_t j = 0; j < no; ++j) {
+            const uint32_t u = q[0], st = q[1];
+            q += 2;
+            conflict |= (u == p0) | (u == p1) | (u == p2);
+            o += st * get(u);
+        }
+        const float *row = tab + o;
+        if constexpr (MAXC <= 2) {
+            const float2 r = *reinterpret_cast<const float2 *>(row);
+            w[0] += r.x;
+            w[1] += r.y;
+        } else {
+#pragma unroll
+            for (int c = 0; c < MAXC; c += 4)
+                if ((uint32_t)c < rowlen) {
+                    const float4 r = *reinterpret_cast<const float4 *>(row + c);
+                    w[c] += r.x; w[c + 1] += r.y; w[c + 2] += r.z; w[c + 3] += r.w;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------- sweep
+// K1: n_steps single-variable updates on every chain of the block.
+//   CPT = false: conditionals computed from the view tables at every update;
+//   CPT = true : conditionals memoised per (variable, blanket configuration)
+//                by k_build_cpt -- one table word per binary update.
+//   TAB_LDS    : tables staged in LDS (else read from global through L1/L2).
+template <int MAXC, bool CPT, bool TAB_LDS>
+__global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint32_t T = blockDim.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t chain = blockIdx.x * T + tid; // local chain index
+    const bool active = chain < p.n_chains;
+    const uint32_t variant = (blockIdx.x * T) / p.chains_per_variant; // blocks never straddle groups
+    const VariantDesc vd = p.variants[variant];
+
+    unsigned char *st = lds + tid;                                    // st[var * T]
+    uint32_t *hist = reinterpret_cast<uint32_t *>(lds + p.lds_hist_off) + wave * p.H; // wave-private
+    const float *tab_f;
+    const uint32_t *tab_u;
+    if constexpr (TAB_LDS) {
+        // stage this group's tables: 16 B per lane per iteration, coalesced
+        const uint32_t n4 = (CPT ? (vd.cpt_len + 3u) : vd.views_len) >> 2;
+        const uint4 *src = CPT ? reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base)
+                               : reinterpret_cast<const uint4 *>(p.views + vd.views_base);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + p.lds_tab_off);
+        for (uint32_t i = tid; i < n4; i += T) dst[i] = src[i];
+        tab_f = reinterpret_cast<const float *>(lds + p.lds_tab_off);
+        tab_u = reinterpret_cast<const uint32_t *>(lds + p.lds_tab_off);
+    } else {
+        tab_f = p.views + vd.views_base;
+        tab_u = p.cpt + vd.cpt_base;
+    }
+    for (uint32_t v = 0; v < p.n_vars; ++v) st[v * T] = active ? p.state[(size_t)v * p.pitch + chain] : (unsigned char)0;
+    for (uint32_t i = lane; i < p.H; i += 64) hist[i] = 0;
+    __syncthreads();
+
+    const unsigned long long amask = __ballot(active);
+    const uint32_t nact = (uint32_t)__popcll(amask);
+    const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
+    const uint32_t wave_gid = uni((uint32_t)(gchain >> 6));
+    const uint64_t step0 = ((uint64_t)p.step0_hi << 32) | p.step0_lo;
+    const uint64_t step1 = step0 + p.n_steps;
+    const uint32_t *progs = (CPT ? p.cprogs + vd.cprog_base : p.progs + vd.prog_base);
+    const uint32_t *poff = (CPT ? p.cprog_off + vd.cprogoff_base : p.prog_off + vd.progoff_base);
+    const uint32_t *freev = p.free_vars + vd.free_base;
+    const bool seq = p.sequential != 0;
+    const bool counting = p.counting != 0;
+
+    auto get = [&](uint32_t u) -> uint32_t { return (uint32_t)st[u * T]; };
+
+    // new value of variable v (program pg) given the current state and the draw u
+    auto sample = [&](const uint32_t *pg, const uint32_t u, const uint32_t p0, const uint32_t p1, const uint32_t p2,
+                      bool &conflict) -> uint32_t {
+        const int C = (int)(pg[0] & 0xffu);
+        if constexpr (CPT) {
+            const uint32_t nn = (pg[0] >> 8) & 0xffu;
+            uint32_t cfg = 0;
+            for (uint32_t j = 0; j < nn; ++j) {
+                const uint32_t nb = pg[3 + 2 * j], mult = pg[4 + 2 * j];
+                conflict |= (nb == p0) | (nb == p1) | (nb == p2);
+                cfg += mult * get(nb);
+            }
+            const uint32_t *row = tab_u + pg[2] + cfg * (uint32_t)(C - 1);
+            uint32_t val = 0;
+#pragma unroll
+            for (int i = 0; i < MAXC - 1; ++i)
+                if (i < C - 1) val += (u >= row[i]) ? 1u : 0u;
+            return val;
+        } else {
+            float w[MAXC];
+            log_weights<MAXC>(pg, tab_f, get, w, p0, p1, p2, conflict);
+            uint32_t Th[MAXC > 1 ? MAXC - 1 : 1];
+            thresholds<MAXC>(w, C, Th);
+            return pick<MAXC>(Th, C, u);
+        }
+    };
+
+    // g.last[v] = val (gibbs-simple.go:267) and Marginal[val] += 1 (chain.go:230-236)
+    auto commit = [&](const uint32_t v, const uint32_t *pg, const uint32_t val) {
+        st[v * T] = (unsigned char)val;
+        if (counting) {
+            const uint32_t C = pg[0] & 0xffu, ho = pg[1];
+            if (C == 2) {
+                const uint32_t ones = (uint32_t)__popcll(__ballot(active && val != 0));
+                if (lane == 0) {
+                    hist[ho] += nact - ones;
+                    hist[ho + 1] += ones;
+                }
+            } else if (active) {
+                atomicAdd(&hist[ho + val], 1u);
+            }
+        }
+    };
+
+    for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
+        const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
+        // which variable each of the next 4 steps updates: wave-uniform stream -> SALU
+        const u32x4 sc = philox4x32_10(q_lo, q_hi, wave_gid, DOM_SCAN, p.seed_lo, p.seed_hi);
+        // the 4 categorical draws of this chain
+        const u32x4 dr = philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
+        const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w};
+        const uint32_t du[4] = {dr.x, dr.y, dr.z, dr.w};
+        uint32_t v[4];
+        const uint32_t *pg[4];
+        bool valid[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t s = (q << 2) + j;
+            valid[j] = (s >= step0) && (s < step1);
+            v[j] = freev[uni(mul_hi_u32(uni(su[j]), vd.n_free))]; // VarSample: uniform over the selectable variables
+            pg[j] = progs + poff[v[j]];
+        }
+        // Phase A: conditionals of all 4 steps from the current state.  Step j's
+        // result is exact unless an earlier step of the quad updates one of its
+        // neighbours (then `conf[j]`); updates of non-adjacent variables commute.
+        uint32_t nv[4] = {0, 0, 0, 0};
+        bool conf[4] = {true, true, true, true};
+        if (!seq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (valid[j]) {
+                    bool c = false;
+                    nv[j] = sample(pg[j], du[j], j > 0 ? v[0] : 0xffffffffu, j > 1 ? v[1] : 0xffffffffu,
+                                   j > 2 ? v[2] : 0xffffffffu, c);
+                    conf[j] = c;
+                }
+        }
+        // Phase B: commit in order; recompute the (rare) steps that did not commute.
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (valid[j]) {
+                if (conf[j]) {
+                    bool c = false;
+                    nv[j] = sample(pg[j], du[j], 0xffffffffu, 0xffffffffu, 0xffffffffu, c);
+                }
+                commit(v[j], pg[j], nv[j]);
+            }
+    }
+
+    // flush: state back to HBM (coalesced rows), wave-private histograms -> global counts
+    for (uint32_t vv = 0; vv < p.n_vars; ++vv)
+        if (active) p.state[(size_t)vv * p.pitch + chain] = st[vv * T];
+    if (counting) {
+        unsigned long long *gc = p.counts + (size_t)variant * p.H;
+        for (uint32_t i = lane; i < p.H; i += 64) {
+            const uint32_t c = hist[i];
+            if (c) atomicAdd(&gc[i], (unsigned long long)c);
+        }
+    }
+}
+
+// K3: start state (gibbs-simple.go:84-112 / 132-142): evidence value, else
+// uniform over [0, Card).  `epoch` separates the re-draw after a collapse.
+__global__ void k_init_state(unsigned char *state, const int32_t *card, const int32_t *fixed, uint32_t n_vars, uint32_t pitch,
+                             uint32_t chain_begin, uint32_t chain_end, uint64_t chain_offset, uint32_t seed_lo, uint32_t seed_hi,
+                             uint32_t epoch) {
+    const uint32_t chain = chain_begin + blockIdx.x * blockDim.x + threadIdx.x;
+    if (chain >= chain_end) return;
+    const uint64_t g = chain_offset + chain;
+    for (uint32_t v0 = 0; v0 < n_vars; v0 += 4) {
+        const u32x4 r = philox4x32_10(v0 >> 2, epoch, (uint32_t)g, DOM_INIT + ((uint32_t)(g >> 32) << 4), seed_lo, seed_hi);
+        const uint32_t rr[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t v = v0 + j;
+            if (v < n_vars) {
+                const int f = fixed[v];
+                state[(size_t)v * pitch + chain] = (unsigned char)(f >= 0 ? (uint32_t)f : mul_hi_u32(rr[j], (uint32_t)card[v]));
+            }
+        }
+    }
+}
+
+// K5: memoise the conditional of every (variable, blanket configuration):
+// thread = one configuration of blockIdx.y's blanket; writes Card-1 thresholds.
+template <int MAXC>
+__global__ void k_build_cpt(const VariantDesc vd, const uint32_t *progs_all, const uint32_t *prog_off_all, const float *views_all,
+                            const uint32_t *cprogs_all, const uint32_t *cprog_off_all, uint32_t *cpt_all, const int32_t *card,
+                            const int32_t *fixed) {
+    const uint32_t v = blockIdx.y;
+    const uint32_t *cp = cprogs_all + vd.cprog_base + cprog_off_all[vd.cprogoff_base + v];
+    const uint32_t *pg = progs_all + vd.prog_base + prog_off_all[vd.progoff_base + v];
+    if ((pg[0] >> 16) == 0) return; // not selectable
+    const int C = (int)(cp[0] & 0xffu);
+    const uint32_t nn = (cp[0] >> 8) & 0xffu;
+    uint32_t ncfg = 1;
+    for (uint32_t j = 0; j < nn; ++j) ncfg *= (uint32_t)card[cp[3 + 2 * j]];
+    const uint32_t cfg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cfg >= ncfg) return;
+    auto get = [&](uint32_t u) -> uint32_t {
+        if (fixed[u] >= 0) return (uint32_t)fixed[u];
+        for (uint32_t j = 0; j < nn; ++j)
+            if (cp[3 + 2 * j] == u) return (cfg / cp[4 + 2 * j]) % (uint32_t)card[u];
+        return 0u;
+    };
+    float w[MAXC];
+    bool c = false;
+    log_weights<MAXC>(pg, views_all + vd.views_base, get, w, 0xffffffffu, 0xffffffffu, 0xffffffffu, c);
+    uint32_t Th[MAXC > 1 ? MAXC - 1 : 1];
+    thresholds<MAXC>(w, C, Th);
+    uint32_t *row = cpt_all + vd.cpt_base + cp[2] + cfg * (uint32_t)(C - 1);
+#pragma unroll
+    for (int i = 0; i < MAXC - 1; ++i)
+        if (i < C - 1) row[i] = Th[i];
+}
+
+// Probe: the conditional the sampling kernels use, for one variable and one
+// explicit state (gr_conditional).  One thread.
+template <int MAXC>
+__global__ void k_conditional(const VariantDesc vd, const uint32_t *progs_all, const uint32_t *prog_off_all, const float *views_all,
+                              uint32_t v, const int32_t *state, double *probs) {
+    const uint32_t *pg = progs_all + vd.prog_base + prog_off_all[vd.progoff_base + v];
+    const int C = (int)(pg[0] & 0xffu);
+    auto get = [&](uint32_t u) -> uint32_t { return (uint32_t)state[u]; };
+    float w[MAXC];
+    bool c = false;
+    log_weights<MAXC>(pg, views_all + vd.views_base, get, w, 0xffffffffu, 0xffffffffu, 0xffffffffu, c);
+    uint32_t Th[MAXC > 1 ? MAXC - 1 : 1];
+    thresholds<MAXC>(w, C, Th);
+    double prev = 0.0;
+    for (int i = 0; i < C; ++i) {
+        const double cur = (i < C - 1) ? (double)Th[i < MAXC - 1 ? i : 0] : 4294967296.0;
+        probs[i] = (cur - prev) / 4294967296.0;
+        prev = cur;
+    }
+}
+
+// K2: Collapse (gibbs-collapsed.go:206-272).  Thread = one entry e of the new
+// factor (a configuration of the blanket minus the variable).  For every value
+// of the collapsed variable: p = exp(sum of its factors' log potentials);
+// new[e] = sum_val p; partial marginals are reduced per block (fixed order).
+// Entries that contradict evidence are never enumerated by the reference's
+// VariableIter(honorFixed) and stay 0.
+
+__global__ void __launch_bounds__(256) k_collapse(const CollapseArgs a) {
+    __shared__ double red[256];
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t digits[32];
+    bool enumerated = e < a.n_entries;
+    if (enumerated) {
+        uint32_t r = e;
+        for (int k = (int)a.n_new - 1; k >= 0; --k) { // last variable fastest
+            digits[k] = r % a.new_card[k];
+            r /= a.new_card[k];
+            if (a.new_fixed[k] >= 0 && (uint32_t)a.new_fixed[k] != digits[k]) enumerated = false;
+        }
+    }
+    double entry = 0.0;
+    for (uint32_t val = 0; val < a.card_v; ++val) {
+        double p = 0.0;
+        if (enumerated) {
+            double s = 0.0;
+            for (uint32_t f = 0; f < a.n_fac; ++f) {
+                uint32_t idx = 0;
+                for (uint32_t j = a.fac_off[f]; j < a.fac_off[f + 1]; ++j)
+                    idx += a.fac_stride[j] * (a.fac_pos[j] < 0 ? val : digits[a.fac_pos[j]]);
+                s += a.tables[a.fac_tab[f] + idx];
+            }
+            p = exp(s);
+            entry += p;
+        }
+        red[threadIdx.x] = p;
+        __syncthreads();
+        for (uint32_t w = 128; w > 0; w >>= 1) {
+            if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) a.out_partial[(size_t)blockIdx.x * a.card_v + val] = red[0];
+        __syncthreads();
+    }
+    if (e < a.n_entries) {
+        double t = entry;
+        if (t < 1e-6) t += 1e-6;
+        a.out_table[e] = log(t);
+    }
+}
+
+// ------------------------------------------------------------ host launchers
+#define GR_DISPATCH_MAXC(maxc, ...)                       \
+    do {                                                    \
+        if ((maxc) <= 2) { constexpr int MC = 2; __VA_ARGS__; }    \
+        else if ((maxc) <= 4) { constexpr int MC = 4; __VA_ARGS__; } \
+        else if ((maxc) <= 8) { constexpr int MC = 8; __VA_ARGS__; } \
+        else if ((maxc) <= 16) { constexpr int MC = 16; __VA_ARGS__; } \
+        else if ((maxc) <= 32) { constexpr int MC = 32; __VA_ARGS__; } \
+        else { constexpr int MC = 64; __VA_ARGS__; }               \
+    } while (0)
+
+template <int MC, bool CPT, bool TL>
+static hipError_t launch_sweep_t(const SweepParams &p, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<MC, CPT, TL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_sweep<MC, CPT, TL>), dim3(blocks), dim3(threads), lds, s, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, uint32_t blocks, uint32_t threads,
+                        uint32_t lds_bytes, hipStream_t s) {
+    hipError_t e = hipSuccess;
+    GR_DISPATCH_MAXC(max_card, {
+        if (cpt) e = tab_lds ? launch_sweep_t<MC, true, true>(p, blocks, threads, lds_bytes, s)
+                             : launch_sweep_t<MC, true, false>(p, blocks, threads, lds_bytes, s);
+        else e = tab_lds ? launch_sweep_t<MC, false, true>(p, blocks, threads, lds_bytes, s)
+                         : launch_sweep_t<MC, false, false>(p, blocks, threads, lds_bytes, s);
+    });
+    return e;
+}
+
+hipError_t launch_init_state(unsigned char *state, const int32_t *card, const int32_t *fixed, uint32_t n_vars, uint32_t pitch,
+                             uint32_t chain_begin, uint32_t chain_end, uint64_t chain_offset, uint64_t seed, uint32_t epoch,
+                             hipStream_t s) {
+    const uint32_t n = chain_end - chain_begin;
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_init_state, dim3((n + 255) / 256), dim3(256), 0, s, state, card, fixed, n_vars, pitch, chain_begin,
+                       chain_end, chain_offset, (uint32_t)seed, (uint32_t)(seed >> 32), epoch);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_cpt(const VariantDesc &vd, const uint32_t *progs, const uint32_t *prog_off, const float *views,
+                            const uint32_t *cprogs, const uint32_t *cprog_off, uint32_t *cpt, const int32_t *card,
+                            const int32_t *fixed, uint32_t n_vars, uint32_t max_cfg, int max_card, hipStream_t s) {
+    const dim3 grid((max_cfg + 127) / 128, n_vars);
+    GR_DISPATCH_MAXC(max_card, {
+        hipLaunchKernelGGL((k_build_cpt<MC>), grid, dim3(128), 0, s, vd, progs, prog_off, views, cprogs, cprog_off, cpt, card, fixed);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_conditional(const VariantDesc &vd, const uint32_t *progs, const uint32_t *prog_off, const float *views,
+                              uint32_t v, const int32_t *state, double *probs, int max_card, hipStream_t s) {
+    GR_DISPATCH_MAXC(max_card, {
+        hipLaunchKernelGGL((k_conditional<MC>), dim3(1), dim3(1), 0, s, vd, progs, prog_off, views, v, state, probs);
+    });
+    return hipGetLastError();
+}
+
+hipError_t launch_collapse(const CollapseArgs &a, uint32_t blocks, hipStream_t s) {
+    hipLaunchKernelGGL(k_collapse, dim3(blocks), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+} // namespace gr

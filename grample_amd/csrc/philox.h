@@ -1,0 +1,57 @@
+// Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy
+// as 1, 2, 3", SC'11) -- counter-based generator used for every random choice
+// on the device.  Replaces the reference's shared MT19937-64 stream
+// (rand/rand.go:19-54): a draw is a pure function of (seed, chain, step), so
+// results do not depend on launch geometry, chunking or the number of GPUs.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define GR_HD __host__ __device__ __forceinline__
+#else
+#define GR_HD inline
+#endif
+
+namespace gr {
+
+constexpr uint32_t PHILOX_M0 = 0xD2511F53u;
+constexpr uint32_t PHILOX_M1 = 0xCD9E8D57u;
+constexpr uint32_t PHILOX_W0 = 0x9E3779B9u;
+constexpr uint32_t PHILOX_W1 = 0xBB67AE85u;
+
+// counter word 3 selects the stream ("domain"); words 0..1 carry the 64-bit
+// position inside the stream, word 2 the chain / wave / variant index.
+enum : uint32_t {
+    DOM_DRAW = 1,     // per chain, per 4 steps: the categorical draws
+    DOM_SCAN = 2,     // per wavefront, per 4 steps: which variable to update
+    DOM_INIT = 3,     // per chain, per variable: start state
+    DOM_COLLAPSE = 4, // per variant, per try: Collapse(-1) selection
+};
+
+struct u32x4 {
+    uint32_t x, y, z, w;
+};
+
+GR_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+        const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += PHILOX_W0;
+        k1 += PHILOX_W1;
+    }
+    return u32x4{c0, c1, c2, c3};
+}
+
+// uniform integer in [0, n) from a 32-bit word: floor(u * n / 2^32).  The
+// selection probabilities differ from 1/n by at most n/2^32 (2.3e-8 for n=100);
+// a random-scan Gibbs chain has the same stationary law for any positive
+// selection probabilities, so this never biases a marginal.
+GR_HD uint32_t mul_hi_u32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+
+} // namespace gr

@@ -1,0 +1,797 @@
+// C-ABI implementation (include/grample_hip.h): host orchestration of the
+// gfx950 Gibbs kernels.  No CPU sampling path exists in this library.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/grample_hip.h"
+#include "compiled_model.hpp"
+#include "device_layout.h"
+#include "host_model.hpp"
+#include "kernels.h"
+#include "philox.h"
+
+using namespace gr;
+
+#define GR_VISIBLE __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+
+void hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw Error(GR_E_NO_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+template <class F>
+int guarded(F &&f) {
+    try {
+        f();
+        return GR_OK;
+    } catch (const Error &e) {
+        return fail(e.code, e.what());
+    } catch (const std::exception &e) {
+        return fail(GR_E_INVALID, e.what());
+    }
+}
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { reset(); }
+    void reset() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void alloc(size_t count) {
+        reset();
+        n = count;
+        hip_check(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T)), "hipMalloc");
+    }
+    void upload(const std::vector<T> &h, hipStream_t s) {
+        alloc(h.size());
+        if (!h.empty()) hip_check(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s), "hipMemcpy H2D");
+    }
+};
+
+constexpr uint32_t kLdsBudget = 160 * 1024;   // LDS per CU on gfx950
+constexpr uint32_t kMaxStepsPerLaunch = 1u << 20; // keeps the u32 wave histograms far from overflow
+
+} // namespace
+
+struct gr_model {
+    Model m;
+};
+struct gr_solution {
+    std::vector<Variable> vars;
+};
+
+struct gr_sampler {
+    gr_sampler_opts o{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_vars = 0, H = 0, max_card = 0;
+    std::vector<int32_t> card, fixed;
+    std::vector<Model> vmodel;        // one log-space clone per chain group (root.go:385, gibbs-simple.go:72-76)
+    std::vector<VariantImage> image;
+    std::vector<uint32_t> epoch;      // start-state re-draw counter per group
+    bool dirty = true;                // device pools need rebuilding
+    bool started = false;             // any burn-in / advance done
+    // configuration
+    uint32_t T = 0, blocks = 0, lds = 0, lds_hist_off = 0, lds_tab_off = 0, pitch = 0, cpv = 0;
+    bool cpt = false, tab_lds = false;
+    // device pools
+    DevBuf<VariantDesc> d_variants;
+    DevBuf<uint32_t> d_progs, d_prog_off, d_free, d_cprogs, d_cprog_off, d_cpt;
+    DevBuf<float> d_views;
+    DevBuf<int32_t> d_card, d_fixed;
+    DevBuf<unsigned char> d_state;
+    DevBuf<unsigned long long> d_counts;
+    std::vector<VariantDesc> h_variants;
+    uint64_t step = 0, counted = 0;
+    double kernel_ms_last = 0;
+    uint32_t launches_last = 0;
+
+    ~gr_sampler() {
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    void use() { hip_check(hipSetDevice(o.device), "hipSetDevice"); }
+    void sync() { hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+
+    void configure();
+    void rebuild();
+    void init_state(uint32_t variant);
+    void run(uint64_t updates, bool counting);
+};
+
+// Pick block size, LDS layout and conditional path for the current images.
+void gr_sampler::configure() {
+    cpv = o.n_chains / o.n_variants;
+    uint32_t views_max = 0, cpt_max = 0;
+    bool all_cpt = !(o.flags & GR_FLAG_DIRECT);
+    for (const auto &im : image) {
+        views_max = std::max<uint32_t>(views_max, (uint32_t)im.views.size());
+        cpt_max = std::max<uint32_t>(cpt_max, (im.cpt_words + 3u) & ~3u);
+        all_cpt = all_cpt && im.cpt_ok;
+    }
+    auto layout = [&](uint32_t t, bool use_cpt, bool tl, uint32_t &hist_off, uint32_t &tab_off) -> uint32_t {
+        uint32_t b = (uint32_t)n_vars * t;
+        b = (b + 15u) & ~15u;
+        hist_off = b;
+        b += (t / 64u) * (uint32_t)H * 4u;
+        b = (b + 15u) & ~15u;
+        tab_off = b;
+        if (tl) b += (use_cpt ? cpt_max : views_max) * 4u;
+        return b;
+    };
+    std::vector<uint32_t> cands;
+    if (o.block_threads) {
+        if (o.block_threads != 64 && o.block_threads != 128 && o.block_threads != 256)
+            throw Error(GR_E_INVALID, "block_threads must be 0, 64, 128 or 256");
+        cands = {o.block_threads};
+    } else {
+        // 256-lane blocks share one staged table copy between 4 waves; use them once
+        // every CU gets a block anyway, otherwise spread single-wave blocks.
+        if (o.n_chains >= 65536) cands = {256, 128, 64};
+        else cands = {64};
+    }
+    for (int pass = 0; pass < 2; ++pass) { // pass 0: memoised path if allowed, pass 1: direct
+        const bool use_cpt = (pass == 0) && all_cpt;
+        if (pass == 0 && !use_cpt) continue;
+        for (bool tl : {true, false}) {
+            if (use_cpt && !tl) continue; // memoised tables are only worth it from LDS
+            for (uint32_t t : cands) {
+                if (o.n_variants > 1 && cpv % t) continue;
+                uint32_t ho, to;
+                const uint32_t b = layout(t, use_cpt, tl, ho, to);
+                if (b > kLdsBudget) continue;
+                T = t; lds = b; lds_hist_off = ho; lds_tab_off = to; cpt = use_cpt; tab_lds = tl;
+                blocks = (o.n_chains + T - 1) / T;
+                return;
+            }
+        }
+    }
+    throw Error(GR_E_UNSUPPORTED, "model does not fit the LDS-resident chain-state layout (n_vars * 64 bytes > 160 KiB)");
+}
+
+// Concatenate the per-group images into the device pools and (re)build the
+// memoised conditional tables on the device.
+void gr_sampler::rebuild() {
+    use();
+    configure();
+    std::vector<uint32_t> progs, prog_off, freev, cprogs, cprog_off;
+    std::vector<float> views;
+    h_variants.assign(o.n_variants, VariantDesc{});
+    uint32_t cpt_total = 0;
+    for (uint32_t g = 0; g < o.n_variants; ++g) {
+        const VariantImage &im = image[g];
+        VariantDesc &vd = h_variants[g];
+        vd.prog_base = (uint32_t)progs.size();
+        vd.progoff_base = (uint32_t)prog_off.size();
+        vd.views_base = (uint32_t)views.size();
+        vd.views_len = (uint32_t)im.views.size();
+        vd.free_base = (uint32_t)freev.size();
+        vd.n_free = (uint32_t)im.free_vars.size();
+        vd.cprog_base = (uint32_t)cprogs.size();
+        vd.cprogoff_base = (uint32_t)cprog_off.size();
+        vd.cpt_base = cpt_total;
+        vd.cpt_len = cpt ? im.cpt_words : 0u;
+        progs.insert(progs.end(), im.prog.begin(), im.prog.end());
+        prog_off.insert(prog_off.end(), im.prog_off.begin(), im.prog_off.end());
+        views.insert(views.end(), im.views.begin(), im.views.end());
+        freev.insert(freev.end(), im.free_vars.begin(), im.free_vars.end());
+        cprogs.insert(cprogs.end(), im.cprog.begin(), im.cprog.end());
+        cprog_off.insert(cprog_off.end(), im.cprog_off.begin(), im.cprog_off.end());
+        if (cpt) cpt_total += (im.cpt_words + 3u) & ~3u;
+    }
+    d_variants.upload(h_variants, stream);
+    d_progs.upload(progs, stream);
+    d_prog_off.upload(prog_off, stream);
+    d_views.upload(views, stream);
+    d_free.upload(freev, stream);
+    d_cprogs.upload(cprogs, stream);
+    d_cprog_off.upload(cprog_off, stream);
+    d_cpt.alloc(cpt_total + 4);
+    hip_check(hipMemsetAsync(d_cpt.p, 0, (cpt_total + 4) * sizeof(uint32_t), stream), "hipMemset");
+    if (cpt)
+        for (uint32_t g = 0; g < o.n_variants; ++g)
+            hip_check(launch_build_cpt(h_variants[g], d_progs.p, d_prog_off.p, d_views.p, d_cprogs.p, d_cprog_off.p, d_cpt.p,
+                                       d_card.p, d_fixed.p, (uint32_t)n_vars, std::max(1u, image[g].max_cfg), max_card, stream),
+                      "k_build_cpt");
+    sync();
+    dirty = false;
+}
+
+void gr_sampler::init_state(uint32_t variant) {
+    use();
+    const uint32_t b = variant * cpv, e = (variant + 1 == o.n_variants) ? o.n_chains : b + cpv;
+    hip_check(launch_init_state(d_state.p, d_card.p, d_fixed.p, (uint32_t)n_vars, pitch, b, e, o.chain_offset, o.seed,
+                                epoch[variant], stream),
+              "k_init_state");
+}
+
+void gr_sampler::run(uint64_t updates, bool counting) {
+    use();
+    if (dirty) rebuild();
+    started = true;
+    kernel_ms_last = 0;
+    launches_last = 0;
+    if (updates == 0) return;
+    SweepParams p{};
+    p.variants = d_variants.p;
+    p.progs = d_progs.p; p.prog_off = d_prog_off.p; p.views = d_views.p; p.free_vars = d_free.p;
+    p.cprogs = d_cprogs.p; p.cprog_off = d_cprog_off.p; p.cpt = d_cpt.p;
+    p.state = d_state.p; p.counts = d_counts.p;
+    p.n_vars = (uint32_t)n_vars; p.H = (uint32_t)H; p.n_chains = o.n_chains; p.pitch = pitch;
+    p.chains_per_variant = cpv;
+    p.chain_offset_lo = (uint32_t)o.chain_offset; p.chain_offset_hi = (uint32_t)(o.chain_offset >> 32);
+    p.seed_lo = (uint32_t)o.seed; p.seed_hi = (uint32_t)(o.seed >> 32);
+    p.counting = counting ? 1u : 0u;
+    p.sequential = (o.flags & GR_FLAG_SEQUENTIAL) ? 1u : 0u;
+    p.lds_hist_off = lds_hist_off; p.lds_tab_off = lds_tab_off;
+    hip_check(hipEventRecord(ev0, stream), "hipEventRecord");
+    uint64_t left = updates;
+    while (left) {
+        const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
+        p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
+        p.n_steps = n;
+        hip_check(launch_sweep(p, max_card, cpt, tab_lds, blocks, T, lds, stream), "k_sweep launch");
+        step += n;
+        left -= n;
+        launches_last++;
+    }
+    hip_check(hipEventRecord(ev1, stream), "hipEventRecord");
+    sync();
+    float ms = 0;
+    hip_check(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
+    kernel_ms_last = ms;
+    if (counting) counted += updates;
+}
+
+// ============================================================== C ABI: general
+extern "C" {
+
+GR_VISIBLE const char *gr_version(void) { return "grample-hip 0.1 (gfx950)"; }
+GR_VISIBLE const char *gr_last_error(void) { return g_err.c_str(); }
+
+GR_VISIBLE int gr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+GR_VISIBLE void gr_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    const u32x4 r = philox4x32_10(ctr[0], ctr[1], ctr[2], ctr[3], key[0], key[1]);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+// ================================================================ model
+GR_VISIBLE gr_model *gr_model_create(const gr_model_desc *d) {
+    gr_model *out = nullptr;
+    guarded([&] {
+        if (!d || !d->card || !d->scope_off || !d->scope_var || !d->tab_off || !d->table) throw Error(GR_E_INVALID, "null model description");
+        if (d->n_vars < 1) throw Error(GR_E_INVALID, "Invalid variable count: " + std::to_string(d->n_vars));
+        if (d->n_funcs < 1) throw Error(GR_E_INVALID, "Invalid Clique count count: " + std::to_string(d->n_funcs));
+        auto gm = std::make_unique<gr_model>();
+        Model &m = gm->m;
+        m.Type = "MARKOV";
+        for (int i = 0; i < d->n_vars; ++i) {
+            m.Vars.push_back(Variable::New(i, d->card[i]));
+            if (d->fixed) m.Vars.back().FixedVal = d->fixed[i];
+        }
+        for (int f = 0; f < d->n_funcs; ++f) {
+            std::vector<int> sc(d->scope_var + d->scope_off[f], d->scope_var + d->scope_off[f + 1]);
+            for (int v : sc)
+                if (v < 0 || v >= d->n_vars) throw Error(GR_E_INVALID, "Invalid var idx " + std::to_string(v) + " for Clique " + std::to_string(f));
+            Function fn = m.NewFunction(f, sc);
+            if ((int)fn.Table.size() != d->tab_off[f + 1] - d->tab_off[f]) throw Error(GR_E_INVALID, "Read table size != previous Clique size on function " + fn.Name);
+            std::copy(d->table + d->tab_off[f], d->table + d->tab_off[f + 1], fn.Table.begin());
+            m.Funcs.push_back(std::move(fn));
+        }
+        m.Check();
+        out = gm.release();
+    });
+    return out;
+}
+
+GR_VISIBLE gr_model *gr_model_from_uai(const char *text, size_t len) {
+    gr_model *out = nullptr;
+    guarded([&] {
+        auto gm = std::make_unique<gr_model>();
+        gm->m = NewModelFromBuffer(std::string(text ? text : "", text ? len : 0));
+        out = gm.release();
+    });
+    return out;
+}
+
+GR_VISIBLE gr_model *gr_model_from_file(const char *path, int use_evidence) {
+    gr_model *out = nullptr;
+    guarded([&] {
+        auto gm = std::make_unique<gr_model>();
+        gm->m = NewModelFromFile(path ? path : "", use_evidence != 0);
+        out = gm.release();
+    });
+    return out;
+}
+
+GR_VISIBLE int gr_model_apply_evidence(gr_model *m, const char *text, size_t len) {
+    return guarded([&] {
+        if (!m) throw Error(GR_E_INVALID, "null model");
+        UAIReader::ApplyEvidence(std::string(text ? text : "", text ? len : 0), m->m);
+    });
+}
+
+GR_VISIBLE gr_model *gr_model_clone(const gr_model *m) {
+    if (!m) { fail(GR_E_INVALID, "null model"); return nullptr; }
+    return new gr_model{m->m};
+}
+GR_VISIBLE void gr_model_destroy(gr_model *m) { delete m; }
+GR_VISIBLE int gr_model_n_vars(const gr_model *m) { return m ? (int)m->m.Vars.size() : fail(GR_E_INVALID, "null model"); }
+GR_VISIBLE int gr_model_n_funcs(const gr_model *m) { return m ? (int)m->m.Funcs.size() : fail(GR_E_INVALID, "null model"); }
+GR_VISIBLE int gr_model_total_card(const gr_model *m) { return m ? m->m.TotalCard() : fail(GR_E_INVALID, "null model"); }
+GR_VISIBLE int gr_model_cards(const gr_model *m, int32_t *out) {
+    if (!m || !out) return fail(GR_E_INVALID, "null argument");
+    for (size_t i = 0; i < m->m.Vars.size(); ++i) out[i] = m->m.Vars[i].Card;
+    return GR_OK;
+}
+GR_VISIBLE int gr_model_fixed(const gr_model *m, int32_t *out) {
+    if (!m || !out) return fail(GR_E_INVALID, "null argument");
+    for (size_t i = 0; i < m->m.Vars.size(); ++i) out[i] = m->m.Vars[i].FixedVal;
+    return GR_OK;
+}
+static const Function *get_func(const gr_model *m, int f) {
+    if (!m || f < 0 || f >= (int)m->m.Funcs.size()) { fail(GR_E_INVALID, "bad function index"); return nullptr; }
+    return &m->m.Funcs[f];
+}
+GR_VISIBLE int gr_model_func_arity(const gr_model *m, int f) { auto *fn = get_func(m, f); return fn ? (int)fn->Vars.size() : GR_E_INVALID; }
+GR_VISIBLE int gr_model_func_tabsize(const gr_model *m, int f) { auto *fn = get_func(m, f); return fn ? (int)fn->Table.size() : GR_E_INVALID; }
+GR_VISIBLE int gr_model_func_scope(const gr_model *m, int f, int32_t *out) {
+    auto *fn = get_func(m, f);
+    if (!fn || !out) return GR_E_INVALID;
+    std::copy(fn->Vars.begin(), fn->Vars.end(), out);
+    return GR_OK;
+}
+GR_VISIBLE int gr_model_func_table(const gr_model *m, int f, double *out) {
+    auto *fn = get_func(m, f);
+    if (!fn || !out) return GR_E_INVALID;
+    std::copy(fn->Table.begin(), fn->Table.end(), out);
+    return GR_OK;
+}
+GR_VISIBLE int gr_model_func_eval(const gr_model *m, int f, const int32_t *values, int n_values, double *out) {
+    if (out) *out = NAN;
+    auto *fn = get_func(m, f);
+    if (!fn || !out || (n_values > 0 && !values)) return GR_E_INVALID;
+    return guarded([&] { *out = m->m.Eval(*fn, values, n_values); });
+}
+
+// ============================================================== solution
+GR_VISIBLE gr_solution *gr_solution_from_text(const char *text, size_t len) {
+    gr_solution *out = nullptr;
+    guarded([&] {
+        auto s = std::make_unique<gr_solution>();
+        s->vars = UAIReader::ReadMargSolution(std::string(text ? text : "", text ? len : 0));
+        out = s.release();
+    });
+    return out;
+}
+GR_VISIBLE gr_solution *gr_solution_from_file(const char *path) {
+    gr_solution *out = nullptr;
+    guarded([&] {
+        auto s = std::make_unique<gr_solution>();
+        s->vars = NewSolutionFromFile(path ? path : "");
+        out = s.release();
+    });
+    return out;
+}
+GR_VISIBLE void gr_solution_destroy(gr_solution *s) { delete s; }
+GR_VISIBLE int gr_solution_n_vars(const gr_solution *s) { return s ? (int)s->vars.size() : fail(GR_E_INVALID, "null solution"); }
+GR_VISIBLE int gr_solution_total_card(const gr_solution *s) {
+    if (!s) return fail(GR_E_INVALID, "null solution");
+    int t = 0;
+    for (auto &v : s->vars) t += v.Card;
+    return t;
+}
+GR_VISIBLE int gr_solution_cards(const gr_solution *s, int32_t *out) {
+    if (!s || !out) return fail(GR_E_INVALID, "null argument");
+    for (size_t i = 0; i < s->vars.size(); ++i) out[i] = s->vars[i].Card;
+    return GR_OK;
+}
+GR_VISIBLE int gr_solution_marginals(const gr_solution *s, double *out) {
+    if (!s || !out) return fail(GR_E_INVALID, "null argument");
+    for (auto &v : s->vars) out = std::copy(v.Marginal.begin(), v.Marginal.end(), out);
+    return GR_OK;
+}
+
+GR_VISIBLE int gr_error_suite(int32_t n_vars, const int32_t *card, const int32_t *fixed1, const int32_t *fixed2, const double *m1,
+                              const double *m2, double *out) {
+    return guarded([&] {
+        if (n_vars < 1 || !card || !m1 || !m2 || !out) throw Error(GR_E_INVALID, "null argument");
+        const ErrorSuite es = NewErrorSuite(n_vars, card, fixed1, fixed2, m1, m2);
+        out[0] = es.MeanMeanAbsError; out[1] = es.MeanMaxAbsError; out[2] = es.MeanHellinger; out[3] = es.MeanJSDiverge;
+        out[4] = es.MaxMeanAbsError; out[5] = es.MaxMaxAbsError; out[6] = es.MaxHellinger; out[7] = es.MaxJSDiverge;
+    });
+}
+
+// =============================================================== sampler
+GR_VISIBLE gr_sampler *gr_sampler_create(const gr_model *m, const gr_sampler_opts *opts) {
+    gr_sampler *out = nullptr;
+    guarded([&] {
+        if (!m) throw Error(GR_E_INVALID, "No model supplied");
+        if (!opts || opts->struct_size != sizeof(gr_sampler_opts)) throw Error(GR_E_INVALID, "bad gr_sampler_opts (struct_size)");
+        if (opts->n_chains < 1) throw Error(GR_E_INVALID, "n_chains must be >= 1");
+        if (opts->n_variants < 1 || opts->n_chains % opts->n_variants) throw Error(GR_E_INVALID, "n_chains must be a multiple of n_variants");
+        if (opts->n_variants > 1 && (opts->n_chains / opts->n_variants) % 64) throw Error(GR_E_INVALID, "chains per variant must be a multiple of 64");
+        if (opts->chain_offset % 64) throw Error(GR_E_INVALID, "chain_offset must be a multiple of 64");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+            throw Error(GR_E_NO_DEVICE, "no HIP device: the Gibbs path runs on the GPU only (there is no CPU fallback)");
+        if (opts->device < 0 || opts->device >= ndev) throw Error(GR_E_NO_DEVICE, "device ordinal out of range");
+        auto s = std::make_unique<gr_sampler>();
+        s->o = *opts;
+        s->use();
+        hip_check(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
+        hip_check(hipEventCreate(&s->ev0), "hipEventCreate");
+        hip_check(hipEventCreate(&s->ev1), "hipEventCreate");
+        Model base = m->m; // Model.Clone (root.go:385)
+        base.Check();
+        s->n_vars = (int)base.Vars.size();
+        s->H = base.TotalCard();
+        for (auto &v : base.Vars) {
+            s->card.push_back(v.Card);
+            s->fixed.push_back(v.FixedVal);
+            s->max_card = std::max(s->max_card, v.Card);
+        }
+        if (s->max_card > kMaxSupportedCard) throw Error(GR_E_UNSUPPORTED, "Card > 64 is not supported by this build");
+        for (auto &f : base.Funcs) Model::UseLogSpace(f); // gibbs-simple.go:72-76
+        const VariantImage im = CompileVariant(base, CompileLimits{});
+        s->vmodel.assign(opts->n_variants, base);
+        s->image.assign(opts->n_variants, im);
+        s->epoch.assign(opts->n_variants, 0);
+        s->pitch = (opts->n_chains + 255u) & ~255u;
+        s->d_card.upload(s->card, s->stream);
+        s->d_fixed.upload(s->fixed, s->stream);
+        s->d_state.alloc((size_t)s->n_vars * s->pitch);
+        hip_check(hipMemsetAsync(s->d_state.p, 0, (size_t)s->n_vars * s->pitch, s->stream), "hipMemset");
+        s->d_counts.alloc((size_t)opts->n_variants * s->H);
+        hip_check(hipMemsetAsync(s->d_counts.p, 0, (size_t)opts->n_variants * s->H * sizeof(unsigned long long), s->stream), "hipMemset");
+        s->configure(); // validates the LDS layout early
+        for (uint32_t g = 0; g < opts->n_variants; ++g) s->init_state(g);
+        s->sync();
+        out = s.release();
+    });
+    return out;
+}
+
+GR_VISIBLE void gr_sampler_destroy(gr_sampler *s) {
+    if (!s) return;
+    (void)hipSetDevice(s->o.device);
+    delete s;
+}
+
+GR_VISIBLE int gr_blanket_size(gr_sampler *s, uint32_t variant, int32_t v) {
+    if (!s || variant >= s->o.n_variants || v < 0 || v >= s->n_vars) return fail(GR_E_INVALID, "bad argument");
+    return (int)VarNeighbors(s->vmodel[variant])[v].size();
+}
+GR_VISIBLE int gr_function_count(gr_sampler *s, uint32_t variant, int32_t v) {
+    if (!s || variant >= s->o.n_variants || v < 0 || v >= s->n_vars) return fail(GR_E_INVALID, "bad argument");
+    return (int)VarFuncs(s->vmodel[variant])[v].size();
+}
+
+constexpr int kNeighborVarMax = 12; // gibbs-collapsed.go:93
+
+GR_VISIBLE int gr_collapse(gr_sampler *s, uint32_t variant, int32_t var_idx, int32_t *out_var, double *out_marginal) {
+    return guarded([&] {
+        if (!s) throw Error(GR_E_INVALID, "null sampler");
+        if (variant >= s->o.n_variants) throw Error(GR_E_INVALID, "variant out of range");
+        if (s->started) throw Error(GR_E_STATE, "gr_collapse must precede burn-in / advance");
+        s->use();
+        Model &pgm = s->vmodel[variant];
+        const int N = s->n_vars;
+        const auto nbrs = VarNeighbors(pgm);
+        if (var_idx < 0) { // gibbs-collapsed.go:102-120: up to N tries among free, un-collapsed variables
+            std::vector<int> cand;
+            for (int i = 0; i < N; ++i)
+                if (!pgm.Vars[i].Collapsed && pgm.Vars[i].FixedVal < 0) cand.push_back(i);
+            if (cand.empty()) throw Error(GR_E_COLLAPSE, "Failure selecting random variable to collapse: No Variables to select");
+            const uint32_t gvar = s->o.variant_offset + variant;
+            for (int t = 0; t < N; ++t) {
+                int pick = cand[0];
+                if (cand.size() > 1) {
+                    const u32x4 r = philox4x32_10((uint32_t)t, s->epoch[variant], gvar, DOM_COLLAPSE, (uint32_t)s->o.seed, (uint32_t)(s->o.seed >> 32));
+                    pick = cand[mul_hi_u32(r.x, (uint32_t)cand.size())];
+                }
+                if ((int)nbrs[pick].size() <= kNeighborVarMax) { var_idx = pick; break; }
+            }
+        }
+        if (var_idx < 0) throw Error(GR_E_COLLAPSE, "Failed to randomly select a variable to collapse");
+        if (var_idx >= N) throw Error(GR_E_COLLAPSE, "Invalid variable index: max is " + std::to_string(N - 1));
+        Variable &cv = pgm.Vars[var_idx];
+        if (cv.FixedVal >= 0) throw Error(GR_E_COLLAPSE, "Can not collapse Fixed Val variable " + std::to_string(cv.ID) + ":" + cv.Name);
+        if (cv.Collapsed) throw Error(GR_E_COLLAPSE, "Already collapsed variable " + std::to_string(cv.ID) + ":" + cv.Name);
+        // blanket in ascending id (the reference iterates a Go map: any order is legal there)
+        std::vector<int> newvars;
+        bool self = false;
+        for (int u : nbrs[var_idx]) {
+            if (u == var_idx) self = true; else newvars.push_back(u);
+        }
+        if (!self) throw Error(GR_E_COLLAPSE, "Collapsing variable not in its own blanket");
+        if (newvars.empty()) throw Error(GR_E_COLLAPSE, "New function would have 0 variables");
+        if (newvars.size() > 32) throw Error(GR_E_UNSUPPORTED, "blanket larger than 32 variables");
+        Function post;
+        try {
+            post = pgm.NewFunction((int)pgm.Funcs.size(), newvars); // fails above maxTabSize (function.go:77-79)
+        } catch (const Error &e) {
+            throw Error(GR_E_COLLAPSE, e.what());
+        }
+        post.Name = "COLLAPSE-" + cv.Name;
+        const auto vf = VarFuncs(pgm);
+        // ---- K2 on the device
+        std::vector<uint32_t> new_card, fac_off{0}, fac_stride, fac_tab;
+        std::vector<int32_t> new_fixed, fac_pos;
+        std::vector<double> tables;
+        for (int u : newvars) { new_card.push_back((uint32_t)pgm.Vars[u].Card); new_fixed.push_back(pgm.Vars[u].FixedVal); }
+        for (int fi : vf[var_idx]) {
+            const Function &f = pgm.Funcs[fi];
+            if (!f.IsLog) throw Error(GR_E_COLLAPSE, "Function " + f.Name + " is not set up for Log Space");
+            fac_tab.push_back((uint32_t)tables.size());
+            tables.insert(tables.end(), f.Table.begin(), f.Table.end());
+            std::vector<uint32_t> stride(f.Vars.size());
+            uint32_t d = 1;
+            for (int j = (int)f.Vars.size() - 1; j >= 0; --j) { stride[j] = d; d *= (uint32_t)pgm.Vars[f.Vars[j]].Card; }
+            for (size_t j = 0; j < f.Vars.size(); ++j) {
+                int pos = -1;
+                if (f.Vars[j] != var_idx) pos = (int)(std::find(newvars.begin(), newvars.end(), f.Vars[j]) - newvars.begin());
+                fac_pos.push_back(pos);
+                fac_stride.push_back(stride[j]);
+            }
+            fac_off.push_back((uint32_t)fac_pos.size());
+        }
+        const uint32_t n_entries = (uint32_t)post.Table.size();
+        const uint32_t nblk = (n_entries + 255) / 256;
+        DevBuf<uint32_t> d_new_card, d_fac_off, d_fac_stride, d_fac_tab;
+        DevBuf<int32_t> d_new_fixed, d_fac_pos;
+        DevBuf<double> d_tables, d_out, d_part;
+        d_new_card.upload(new_card, s->stream); d_new_fixed.upload(new_fixed, s->stream);
+        d_fac_off.upload(fac_off, s->stream); d_fac_pos.upload(fac_pos, s->stream);
+        d_fac_stride.upload(fac_stride, s->stream); d_fac_tab.upload(fac_tab, s->stream);
+        d_tables.upload(tables, s->stream);
+        d_out.alloc(n_entries);
+        d_part.alloc((size_t)nblk * cv.Card);
+        CollapseArgs a{};
+        a.n_entries = n_entries; a.card_v = (uint32_t)cv.Card; a.n_new = (uint32_t)newvars.size(); a.n_fac = (uint32_t)vf[var_idx].size();
+        a.new_card = d_new_card.p; a.new_fixed = d_new_fixed.p; a.fac_off = d_fac_off.p; a.fac_pos = d_fac_pos.p;
+        a.fac_stride = d_fac_stride.p; a.fac_tab = d_fac_tab.p; a.tables = d_tables.p; a.out_table = d_out.p; a.out_partial = d_part.p;
+        hip_check(launch_collapse(a, nblk, s->stream), "k_collapse");
+        std::vector<double> part((size_t)nblk * cv.Card);
+        hip_check(hipMemcpyAsync(post.Table.data(), d_out.p, n_entries * sizeof(double), hipMemcpyDeviceToHost, s->stream), "D2H");
+        hip_check(hipMemcpyAsync(part.data(), d_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream), "D2H");
+        s->sync();
+        post.IsLog = true; // the kernel already applied UseLogSpace (gibbs-collapsed.go:269)
+        Variable marg = cv;
+        for (int k = 0; k < cv.Card; ++k) {
+            double acc = 1e-12; // gibbs-collapsed.go:138-140
+            for (uint32_t b = 0; b < nblk; ++b) acc += part[(size_t)b * cv.Card + k];
+            marg.Marginal[k] = acc;
+        }
+        marg.NormMarginal();
+        // ---- model surgery (gibbs-collapsed.go:275-313)
+        std::set<int> del(vf[var_idx].begin(), vf[var_idx].end());
+        std::vector<Function> kept;
+        for (size_t i = 0; i < pgm.Funcs.size(); ++i)
+            if (!del.count((int)i)) kept.push_back(std::move(pgm.Funcs[i]));
+        kept.push_back(std::move(post));
+        pgm.Funcs = std::move(kept);
+        cv.Collapsed = true;
+        cv.Marginal = marg.Marginal;
+        pgm.Check();
+        if (!VarFuncs(pgm)[var_idx].empty()) throw Error(GR_E_COLLAPSE, "Var is collapsed but has a blanket");
+        s->image[variant] = CompileVariant(pgm, CompileLimits{});
+        s->dirty = true;
+        s->configure();
+        s->epoch[variant]++; // base.FunctionsChanged re-draws the start state (gibbs-simple.go:132-142)
+        s->init_state(variant);
+        s->sync();
+        if (out_var) *out_var = var_idx;
+        if (out_marginal) std::copy(cv.Marginal.begin(), cv.Marginal.end(), out_marginal);
+    });
+}
+
+GR_VISIBLE int gr_burnin(gr_sampler *s, uint64_t updates_per_chain) {
+    return guarded([&] { if (!s) throw Error(GR_E_INVALID, "null sampler"); s->run(updates_per_chain, false); });
+}
+GR_VISIBLE int gr_advance(gr_sampler *s, uint64_t updates_per_chain) {
+    return guarded([&] { if (!s) throw Error(GR_E_INVALID, "null sampler"); s->run(updates_per_chain, true); });
+}
+GR_VISIBLE int gr_total_samples(gr_sampler *s, uint64_t *out) {
+    if (!s || !out) return fail(GR_E_INVALID, "null argument");
+    *out = s->counted * (uint64_t)s->o.n_chains;
+    return GR_OK;
+}
+
+GR_VISIBLE int gr_counts(gr_sampler *s, uint64_t *counts, uint64_t *n_updates) {
+    return guarded([&] {
+        if (!s) throw Error(GR_E_INVALID, "null sampler");
+        s->use();
+        if (counts) {
+            hip_check(hipMemcpyAsync(counts, s->d_counts.p, (size_t)s->o.n_variants * s->H * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream), "D2H");
+            s->sync();
+        }
+        if (n_updates) *n_updates = s->counted * (uint64_t)s->o.n_chains;
+    });
+}
+GR_VISIBLE int gr_counts_device(gr_sampler *s, void **dptr, size_t *n_elems) {
+    if (!s || !dptr) return fail(GR_E_INVALID, "null argument");
+    *dptr = s->d_counts.p;
+    if (n_elems) *n_elems = (size_t)s->o.n_variants * s->H;
+    return GR_OK;
+}
+GR_VISIBLE int gr_counts_upload(gr_sampler *s, const uint64_t *counts) {
+    return guarded([&] {
+        if (!s || !counts) throw Error(GR_E_INVALID, "null argument");
+        s->use();
+        hip_check(hipMemcpyAsync(s->d_counts.p, counts, (size_t)s->o.n_variants * s->H * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream), "H2D");
+        s->sync();
+    });
+}
+
+GR_VISIBLE int gr_merge_local(gr_sampler *s, double *out_sum, int32_t *out_coll_variant, double *out_coll_marginal) {
+    return guarded([&] {
+        if (!s || !out_sum || !out_coll_variant || !out_coll_marginal) throw Error(GR_E_INVALID, "null argument");
+        std::vector<uint64_t> cnt((size_t)s->o.n_variants * s->H);
+        if (gr_counts(s, cnt.data(), nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
+        std::fill(out_sum, out_sum + s->H, 0.0);
+        std::fill(out_coll_marginal, out_coll_marginal + s->H, 0.0);
+        const double cpv = (double)(s->o.n_chains / s->o.n_variants);
+        int off = 0;
+        for (int v = 0; v < s->n_vars; ++v) {
+            out_coll_variant[v] = -1;
+            const int C = s->card[v];
+            for (uint32_t g = 0; g < s->o.n_variants; ++g) {
+                const Variable &var = s->vmodel[g].Vars[v];
+                if (var.Collapsed) {
+                    if (out_coll_variant[v] < 0) {
+                        out_coll_variant[v] = (int32_t)(s->o.variant_offset + g);
+                        std::copy(var.Marginal.begin(), var.Marginal.end(), out_coll_marginal + off);
+                    }
+                    continue; // a collapsed variable is never sampled: it contributes no counts
+                }
+                // every chain starts from the uniform marginal 1/Card (variable.go:45) and adds its counts (chain.go:230-236)
+                for (int k = 0; k < C; ++k) out_sum[off + k] += cpv / (double)C + (double)cnt[(size_t)g * s->H + off + k];
+            }
+            off += C;
+        }
+    });
+}
+
+GR_VISIBLE int gr_merge(gr_sampler *const *samplers, int n, double *out_marginal, int32_t *out_collapsed) {
+    return guarded([&] {
+        if (!samplers || n < 1 || !out_marginal) throw Error(GR_E_INVALID, "Can not merge 0 chains");
+        const int H = samplers[0]->H, N = samplers[0]->n_vars;
+        std::vector<double> sum(H), cm(H), tot(H, 0.0), best_m(H, 0.0);
+        std::vector<int32_t> cvv(N), best(N, -1);
+        for (int i = 0; i < n; ++i) {
+            gr_sampler *s = samplers[i];
+            if (!s || s->H != H || s->n_vars != N) throw Error(GR_E_INVALID, "Cannot merge samplers of different models");
+            if (gr_merge_local(s, sum.data(), cvv.data(), cm.data())) throw Error(GR_E_NO_DEVICE, g_err);
+            for (int k = 0; k < H; ++k) tot[k] += sum[k];
+            int off = 0;
+            for (int v = 0; v < N; ++v) {
+                if (cvv[v] >= 0 && (best[v] < 0 || cvv[v] < best[v])) {
+                    best[v] = cvv[v];
+                    std::copy(cm.begin() + off, cm.begin() + off + s->card[v], best_m.begin() + off);
+                }
+                off += s->card[v];
+            }
+        }
+        int off = 0;
+        for (int v = 0; v < N; ++v) {
+            const int C = samplers[0]->card[v];
+            // "collapsed wins" (chain.go:113-129): first collapsed chain's exact marginal, no summation
+            for (int k = 0; k < C; ++k) out_marginal[off + k] = best[v] >= 0 ? best_m[off + k] : tot[off + k];
+            if (out_collapsed) out_collapsed[v] = best[v] >= 0 ? 1 : 0;
+            off += C;
+        }
+    });
+}
+
+GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t *out) {
+    return guarded([&] {
+        if (!samplers || n < 1) throw Error(GR_E_INVALID, "no samplers");
+        const size_t cnt = (size_t)samplers[0]->o.n_variants * samplers[0]->H;
+        std::vector<int> devs(n);
+        for (int i = 0; i < n; ++i) {
+            if (!samplers[i] || (size_t)samplers[i]->o.n_variants * samplers[i]->H != cnt) throw Error(GR_E_INVALID, "samplers differ in shape");
+            devs[i] = samplers[i]->o.device;
+        }
+        if (n > 1) {
+            std::vector<ncclComm_t> comms(n);
+            if (ncclCommInitAll(comms.data(), n, devs.data()) != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclCommInitAll failed");
+            ncclGroupStart();
+            for (int i = 0; i < n; ++i)
+                ncclAllReduce(samplers[i]->d_counts.p, samplers[i]->d_counts.p, cnt, ncclUint64, ncclSum, comms[i], samplers[i]->stream);
+            const ncclResult_t r = ncclGroupEnd();
+            for (int i = 0; i < n; ++i) { samplers[i]->use(); samplers[i]->sync(); }
+            for (int i = 0; i < n; ++i) ncclCommDestroy(comms[i]);
+            if (r != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclAllReduce failed");
+        }
+        if (out && gr_counts(samplers[0], out, nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
+    });
+}
+
+GR_VISIBLE int gr_state(gr_sampler *s, uint32_t chain, int32_t *out) {
+    return guarded([&] {
+        if (!s || !out) throw Error(GR_E_INVALID, "null argument");
+        if (chain >= s->o.n_chains) throw Error(GR_E_INVALID, "chain out of range");
+        s->use();
+        std::vector<unsigned char> col(s->n_vars);
+        hip_check(hipMemcpy2DAsync(col.data(), 1, s->d_state.p + chain, s->pitch, 1, s->n_vars, hipMemcpyDeviceToHost, s->stream), "D2H state");
+        s->sync();
+        for (int v = 0; v < s->n_vars; ++v) out[v] = col[v];
+    });
+}
+GR_VISIBLE int gr_set_state(gr_sampler *s, uint32_t chain, const int32_t *in) {
+    return guarded([&] {
+        if (!s || !in) throw Error(GR_E_INVALID, "null argument");
+        if (chain >= s->o.n_chains) throw Error(GR_E_INVALID, "chain out of range");
+        s->use();
+        std::vector<unsigned char> col(s->n_vars);
+        for (int v = 0; v < s->n_vars; ++v) {
+            if (in[v] < 0 || in[v] >= s->card[v]) throw Error(GR_E_INVALID, "state value out of range");
+            col[v] = (unsigned char)in[v];
+        }
+        hip_check(hipMemcpy2DAsync(s->d_state.p + chain, s->pitch, col.data(), 1, 1, s->n_vars, hipMemcpyHostToDevice, s->stream), "H2D state");
+        s->sync();
+    });
+}
+
+GR_VISIBLE int gr_conditional(gr_sampler *s, uint32_t variant, int32_t v, const int32_t *state, double *probs_out) {
+    return guarded([&] {
+        if (!s || !state || !probs_out) throw Error(GR_E_INVALID, "null argument");
+        if (variant >= s->o.n_variants || v < 0 || v >= s->n_vars) throw Error(GR_E_INVALID, "bad variant / variable");
+        const Variable &var = s->vmodel[variant].Vars[v];
+        if (var.FixedVal >= 0) throw Error(GR_E_INVALID, "Selected sample variable " + var.Name + " which has FixedVal=" + std::to_string(var.FixedVal));
+        if (var.Collapsed) throw Error(GR_E_INVALID, "variable is collapsed");
+        for (int u = 0; u < s->n_vars; ++u)
+            if (state[u] < 0 || state[u] >= s->card[u]) throw Error(GR_E_INVALID, "state value out of range");
+        s->use();
+        if (s->dirty) s->rebuild();
+        DevBuf<int32_t> d_st;
+        DevBuf<double> d_pr;
+        d_st.upload(std::vector<int32_t>(state, state + s->n_vars), s->stream);
+        d_pr.alloc(var.Card);
+        hip_check(launch_conditional(s->h_variants[variant], s->d_progs.p, s->d_prog_off.p, s->d_views.p, (uint32_t)v, d_st.p, d_pr.p, s->max_card, s->stream), "k_conditional");
+        hip_check(hipMemcpyAsync(probs_out, d_pr.p, var.Card * sizeof(double), hipMemcpyDeviceToHost, s->stream), "D2H");
+        s->sync();
+    });
+}
+
+GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
+    return guarded([&] {
+        if (!s || !out || out->struct_size != sizeof(gr_sampler_info)) throw Error(GR_E_INVALID, "bad gr_sampler_info");
+        if (s->dirty) { s->use(); s->configure(); }
+        out->block_threads = s->T; out->n_blocks = s->blocks; out->lds_bytes = s->lds;
+        out->path = s->cpt ? 1u : 0u; out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
+        out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
+    });
+}
+
+} // extern "C"

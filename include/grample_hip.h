@@ -1,0 +1,200 @@
+/*
+ * grample_hip.h -- C ABI of the MI355X-native Gibbs hot path for grample.
+ *
+ * This is the drop-in boundary: a Go host (cgo), a C++ host or Python (ctypes)
+ * binds exactly these symbols.  Plain pointers and sizes only; no C++ or torch
+ * types.  Every entry point cites the reference interface it replaces
+ * (file:line relative to CraigKelly/grample).
+ *
+ * Conventions
+ *   - return 0 = OK, negative = error (GR_E_*); gr_last_error() gives the text
+ *     (thread-local).  Nothing aborts or throws across the ABI.
+ *   - the library never keeps a caller pointer after the call returns (cgo
+ *     pointer rule); outputs are caller-allocated.
+ *   - handles are not thread-safe; distinct handles may be used from distinct
+ *     OS threads (one gr_sampler per device).
+ *   - calls are synchronous: the sampler's HIP stream is synchronised before
+ *     a call returns.
+ *   - there is NO CPU fallback: every sampling entry point fails with
+ *     GR_E_NO_DEVICE when no gfx950 device is usable.
+ */
+#ifndef GRAMPLE_HIP_H
+#define GRAMPLE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GR_OK 0
+#define GR_E_INVALID (-1)    /* bad argument / malformed input (Go: errors.Errorf paths) */
+#define GR_E_NO_DEVICE (-2)  /* no HIP device / HIP runtime failure */
+#define GR_E_UNSUPPORTED (-3)/* valid for the reference, outside this build's limits (e.g. Card > 64) */
+#define GR_E_STATE (-4)      /* call order violation (e.g. collapse after advance) */
+#define GR_E_COLLAPSE (-5)   /* Collapse refused, same cases as gibbs-collapsed.go:122-196 */
+
+typedef struct gr_model gr_model;       /* model.Model (model/model.go:24-29) */
+typedef struct gr_solution gr_solution; /* model.Solution (model/solution.go:16-18) */
+typedef struct gr_sampler gr_sampler;   /* a set of sampler.Chain + their FullSampler on ONE device */
+
+/* ------------------------------------------------------------------ general */
+const char *gr_version(void);
+const char *gr_last_error(void);
+/* number of usable HIP devices (0 when there is none; never an error) */
+int gr_device_count(void);
+
+/* -------------------------------------------------------------------- model
+ * Flat image of what UAIReader.ReadModel builds (model/uai.go:53-179):
+ * table[] holds LINEAR-space values exactly as parsed, last scope variable
+ * fastest (model/function.go:13-36).  fixed may be NULL (= no evidence). */
+typedef struct gr_model_desc {
+    int32_t n_vars;
+    const int32_t *card;      /* [n_vars]  Variable.Card */
+    const int32_t *fixed;     /* [n_vars]  Variable.FixedVal, -1 = free; may be NULL */
+    int32_t n_funcs;
+    const int32_t *scope_off; /* [n_funcs+1] */
+    const int32_t *scope_var; /* [scope_off[n_funcs]] Function.Vars, most significant first */
+    const int32_t *tab_off;   /* [n_funcs+1] */
+    const double *table;      /* [tab_off[n_funcs]] Function.Table */
+} gr_model_desc;
+
+gr_model *gr_model_create(const gr_model_desc *desc);                /* + Model.Check (model.go:115-157) */
+gr_model *gr_model_from_uai(const char *text, size_t len);           /* NewModelFromBuffer (model.go:79-91) */
+gr_model *gr_model_from_file(const char *path, int use_evidence);    /* NewModelFromFile (model.go:52-76) */
+int gr_model_apply_evidence(gr_model *m, const char *text, size_t len); /* UAIReader.ApplyEvidence (uai.go:183-249) */
+gr_model *gr_model_clone(const gr_model *m);                         /* Model.Clone (model.go:32-49) */
+void gr_model_destroy(gr_model *m);
+int gr_model_n_vars(const gr_model *m);
+int gr_model_n_funcs(const gr_model *m);
+int gr_model_total_card(const gr_model *m);                          /* sum of Card = length of a marginal vector */
+int gr_model_cards(const gr_model *m, int32_t *out /*[n_vars]*/);
+int gr_model_fixed(const gr_model *m, int32_t *out /*[n_vars]*/);
+int gr_model_func_arity(const gr_model *m, int f);
+int gr_model_func_tabsize(const gr_model *m, int f);
+int gr_model_func_scope(const gr_model *m, int f, int32_t *out /*[arity]*/);
+int gr_model_func_table(const gr_model *m, int f, double *out /*[tabsize]*/);
+/* Function.Eval (model/function.go:146-157): *out = NaN and GR_E_INVALID on bad input */
+int gr_model_func_eval(const gr_model *m, int f, const int32_t *values, int n_values, double *out);
+
+/* ----------------------------------------------------------------- solution */
+gr_solution *gr_solution_from_text(const char *text, size_t len);    /* ReadMargSolution (uai.go:252-332) */
+gr_solution *gr_solution_from_file(const char *path);                /* NewSolutionFromFile (solution.go:21-33) */
+void gr_solution_destroy(gr_solution *s);
+int gr_solution_n_vars(const gr_solution *s);
+int gr_solution_total_card(const gr_solution *s);
+int gr_solution_cards(const gr_solution *s, int32_t *out);
+int gr_solution_marginals(const gr_solution *s, double *out /*[total_card]*/);
+
+/* model.NewErrorSuite (model/error.go:28-78).  m1/m2 = concatenated marginals
+ * (any positive scale).  fixed1/fixed2 may be NULL.  out[8] = MeanMeanAbsError,
+ * MeanMaxAbsError, MeanHellinger, MeanJSDiverge, MaxMeanAbsError,
+ * MaxMaxAbsError, MaxHellinger, MaxJSDiverge. */
+int gr_error_suite(int32_t n_vars, const int32_t *card, const int32_t *fixed1, const int32_t *fixed2,
+                   const double *m1, const double *m2, double *out);
+
+/* ------------------------------------------------------------------ sampler
+ * One gr_sampler = n_chains independent chains (sampler.Chain, chain.go:13-20)
+ * on one device, in n_variants equal groups.  All chains of a group share one
+ * model clone (root.go:385): group g is what the reference builds with
+ * NewGibbsSimple / NewGibbsCollapsed (+ Collapse) for each of its chains. */
+#define GR_FLAG_DIRECT (1u << 0)      /* never memoise conditionals into tables (debug / cross-check) */
+#define GR_FLAG_SEQUENTIAL (1u << 1)  /* never co-issue commuting updates (debug / cross-check) */
+
+typedef struct gr_sampler_opts {
+    uint32_t struct_size;    /* = sizeof(gr_sampler_opts) */
+    uint32_t n_chains;       /* chains on this device */
+    uint32_t n_variants;     /* chain groups (>=1); n_chains % n_variants == 0 */
+    int32_t device;          /* HIP device ordinal */
+    uint64_t seed;           /* rand.NewGenerator(seed) (rand.go:47-49); Philox4x32-10 key */
+    uint64_t chain_offset;   /* global index of this device's chain 0 (multi-GPU: results do not depend on the split) */
+    uint32_t variant_offset; /* global index of this device's variant 0 */
+    uint32_t flags;          /* GR_FLAG_* */
+    uint32_t block_threads;  /* 0 = auto; else 64/128/256 */
+    uint32_t reserved;
+} gr_sampler_opts;
+
+/* NewGibbsSimple for every chain (gibbs-simple.go:25-115): clones the model,
+ * UseLogSpace on every factor, var->factor adjacency, uniform random start
+ * state honouring evidence.  The model handle may be destroyed afterwards. */
+gr_sampler *gr_sampler_create(const gr_model *m, const gr_sampler_opts *opts);
+void gr_sampler_destroy(gr_sampler *s);
+
+/* (*GibbsCollapsed).Collapse (gibbs-collapsed.go:98-314) applied to the model
+ * of chain group `variant`: var_idx < 0 picks a random tractable variable.
+ * Writes the variable's index and its exact marginal [Card].  Like the
+ * reference it re-draws that group's start state.  Only before sampling. */
+int gr_collapse(gr_sampler *s, uint32_t variant, int32_t var_idx, int32_t *out_var, double *out_marginal);
+/* BlanketSize / FunctionCount (gibbs-collapsed.go:81-88) on a group's current model */
+int gr_blanket_size(gr_sampler *s, uint32_t variant, int32_t var_idx);
+int gr_function_count(gr_sampler *s, uint32_t variant, int32_t var_idx);
+
+/* NewChain's burn-in loop (chain.go:166-172): updates_per_chain single-variable
+ * updates on every chain, nothing counted. */
+int gr_burnin(gr_sampler *s, uint64_t updates_per_chain);
+/* Chain.AdvanceChain + wg.Wait (chain.go:180-218, root.go:476-479) with an
+ * explicit length: updates_per_chain x oneSample(true) on every chain. */
+int gr_advance(gr_sampler *s, uint64_t updates_per_chain);
+/* Chain.TotalSampleCount summed over this sampler's chains (root.go:486-490) */
+int gr_total_samples(gr_sampler *s, uint64_t *out);
+
+/* Raw sample counts: counts[g * total_card + off(v) + val] = number of counted
+ * updates that set v := val in group g.  (Variable.Marginal minus its 1/Card
+ * prior, chain.go:230-236.)  counts may be NULL. */
+int gr_counts(gr_sampler *s, uint64_t *counts /*[n_variants*total_card]*/, uint64_t *n_updates);
+/* device-resident copy of the same array, for an external collective (RCCL
+ * through the host framework): pointer stays valid until destroy. */
+int gr_counts_device(gr_sampler *s, void **dptr, size_t *n_elems);
+int gr_counts_upload(gr_sampler *s, const uint64_t *counts); /* restore (checkpoint/resume) */
+
+/* MergeChains (chain.go:96-148) over all chains of `n` samplers (= devices),
+ * in global variant order: a variable collapsed in ANY group takes the first
+ * such group's exact marginal; otherwise marginal = sum over chains of
+ * (1/Card + counts).  out_marginal [total_card] is NOT normalised (like the
+ * reference); out_collapsed [n_vars] may be NULL. */
+int gr_merge(gr_sampler *const *samplers, int n, double *out_marginal, int32_t *out_collapsed);
+/* Same, but only the device-local half: per-variable partial sums and, for
+ * collapsed variables, the lowest global variant that collapsed them and its
+ * marginal.  Lets a multi-PROCESS host finish the merge with one all-reduce. */
+int gr_merge_local(gr_sampler *s, double *out_sum /*[total_card]*/, int32_t *out_coll_variant /*[n_vars], -1 = none*/,
+                   double *out_coll_marginal /*[total_card]*/);
+/* Sum of the raw count arrays of n samplers living in ONE process, one per
+ * device, with a single ncclAllReduce(sum, uint64) over RCCL; every sampler's
+ * device array then holds the total.  out may be NULL. */
+int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t *out /*[n_variants*total_card]*/);
+
+/* Chain.LastSample of one chain (chain.go:19) */
+int gr_state(gr_sampler *s, uint32_t chain, int32_t *out /*[n_vars]*/);
+int gr_set_state(gr_sampler *s, uint32_t chain, const int32_t *in /*[n_vars]*/);
+
+/* The conditional law GibbsSimple.SampleVar draws from (gibbs-simple.go:175-258)
+ * for variable var_idx of group `variant` given a full state, evaluated ON THE
+ * DEVICE by the same code the sampling kernels use: probs_out[Card]. */
+int gr_conditional(gr_sampler *s, uint32_t variant, int32_t var_idx, const int32_t *state, double *probs_out);
+
+/* Introspection for benchmarks: milliseconds spent in the sweep kernel(s) of the
+ * last gr_burnin/gr_advance call (HIP events on the sampler's stream), number
+ * of launches, and the configuration chosen. */
+typedef struct gr_sampler_info {
+    uint32_t struct_size;
+    uint32_t block_threads;
+    uint32_t n_blocks;
+    uint32_t lds_bytes;
+    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables */
+    uint32_t max_card;
+    uint32_t tables_in_lds;
+    uint32_t n_launches_last;
+    double kernel_ms_last;
+    uint64_t step;          /* updates per chain executed so far (burn-in included) */
+} gr_sampler_info;
+int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out);
+
+/* Philox4x32-10 block function on the host (same code the device runs);
+ * exported so the known-answer vectors can be checked without a GPU. */
+void gr_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRAMPLE_HIP_H */

@@ -1,0 +1,192 @@
+"""GPU tests of the collapsed (Rao-Blackwellised) path: K2 collapse kernel,
+per-variant models, MergeChains' "collapsed wins" rule.  Restates
+sampler/gibbs-collapsed_test.go and sampler/chain_test.go through the C ABI and
+checks the device against the oracle's Collapse.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import grample_amd as g
+from tests import uai_py
+
+pytestmark = pytest.mark.gpu
+
+
+def test_working_gibbs_collapsed(res_dir):
+    """gibbs-collapsed_test.go:14-48: deterministic.uai, each variable collapses to (0.5, 0.5)."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, "deterministic.uai"))
+    for i in range(3):
+        s = g.HIPChains.NewGibbsCollapsed(m, 64, 1)
+        v, marg = s.Collapse(0, i)
+        assert v == i
+        assert marg[0] == pytest.approx(0.5, rel=1e-5) and marg[1] == pytest.approx(0.5, rel=1e-5)
+        _, coll = g.MergeChains([s])
+        assert coll.tolist() == [int(j == i) for j in range(3)]
+
+
+def test_full_gibbs_collapsed_sequencing(res_dir):
+    """gibbs-collapsed_test.go:51-111: sample.uai: Collapse(0), Collapse(1) OK; random twice OK, third errors."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, "sample.uai"))
+    s = g.HIPChains.NewGibbsCollapsed(m, 64, 1)
+    assert s.Collapse(0, 0)[0] == 0
+    assert s.Collapse(0, 1)[0] == 1
+    assert g.MergeChains([s])[1].tolist() == [1, 1, 0]
+    with pytest.raises(g.GrError):
+        s.Collapse(0, 1)  # already collapsed
+    with pytest.raises(g.GrError):
+        s.Collapse(0, 3)  # invalid index
+    s = g.HIPChains.NewGibbsCollapsed(m, 64, 1, seed=42)
+    a, _ = s.Collapse(0, -1)
+    b, _ = s.Collapse(0, -1)
+    assert a != b and sum(g.MergeChains([s])[1]) == 2
+    with pytest.raises(g.GrError) as ei:
+        s.Collapse(0, -1)  # at least one variable must remain
+    assert "0 variables" in str(ei.value)
+    s.BurnIn(10)
+    with pytest.raises(g.GrError):
+        s.Collapse(0, 2)  # only before sampling
+
+
+@pytest.mark.parametrize("name,vars_", [("sample.uai", [0, 1, 2]), ("Grids_13.uai", [0, 37, 99]),
+                                        ("Segmentation_11.uai", [0, 5, 100, 227]), ("ObjectDetection_13.uai", None),
+                                        ("Pedigree_11.uai", None)])
+def test_collapse_matches_oracle(oracle, res_dir, name, vars_):
+    """a15: exact marginal, BlanketSize / FunctionCount, and the NEW FACTOR (checked through the
+    conditionals of the collapsed model at random states) against the oracle's Collapse."""
+    ev = name.startswith("Pedigree")
+    pm = uai_py.load(res_dir, name, ev)
+    L = oracle.lib()
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, name), ev)
+    rng = np.random.default_rng(5)
+    if vars_ is None:  # pick collapsible variables: free, blanket 2..6 keeps card-16 tables under maxTabSize
+        probe = g.HIPChains.NewGibbsCollapsed(gm, 64, 1)
+        vars_ = [v for v in range(len(pm.card)) if pm.fixed[v] < 0 and 2 <= probe.BlanketSize(0, v) <= 6][:4]
+        assert vars_
+    for v in vars_:
+        om = oracle.Model.from_parsed(pm)
+        gen = L.orc_gen_new(1)
+        oc = L.orc_collapsed_new(gen, om.ptr)
+        s = g.HIPChains.NewGibbsCollapsed(gm, 64, 1)
+        assert s.BlanketSize(0, v) == L.orc_collapsed_blanket_size(oc, v)
+        assert s.FunctionCount(0, v) == L.orc_collapsed_function_count(oc, v)
+        rc = L.orc_collapsed_collapse(oc, v)
+        if rc < 0:
+            with pytest.raises(g.GrError):
+                s.Collapse(0, v)
+            continue
+        gv, marg = s.Collapse(0, v)
+        assert gv == v
+        assert np.allclose(marg, om.marginal(v), rtol=1e-10, atol=1e-300)
+        assert s.BlanketSize(0, v) == 0 and s.FunctionCount(0, v) == 0
+        base = L.orc_collapsed_base(oc)
+        free = [u for u in range(len(pm.card)) if pm.fixed[u] < 0 and u != v]
+        for _ in range(60):
+            st = np.array([rng.integers(0, c) if f < 0 else f for c, f in zip(pm.card, pm.fixed)], dtype=np.int32)
+            u = int(rng.choice(free))
+            assert s.BlanketSize(0, u) == L.orc_collapsed_blanket_size(oc, u)
+            pd = s.conditional(0, u, st)
+            po = np.zeros(pm.card[u])
+            assert L.orc_simple_conditional(base, u, st.ctypes.data_as(C.POINTER(C.c_int)), po.ctypes.data_as(C.POINTER(C.c_double))) == 0
+            assert np.all(np.abs(pd - po) <= 4e-10 + 5e-5 * po), (name, v, u, pd, po)
+        with pytest.raises(g.GrError):
+            s.conditional(0, v, st)  # a collapsed variable is not sampled any more
+        L.orc_collapsed_free(oc); L.orc_gen_free(gen)
+
+
+def test_collapse_refusals(res_dir):
+    """gibbs-collapsed.go:130-137,175-177 + function.go:77-79."""
+    pm_path = os.path.join(res_dir, "Pedigree_11.uai")
+    m = g.Model.NewModelFromFile(pm_path, True)
+    fixed = m.fixed()
+    s = g.HIPChains.NewGibbsCollapsed(m, 64, 1)
+    with pytest.raises(g.GrError):
+        s.Collapse(0, int(np.where(fixed >= 0)[0][0]))  # evidence variable
+    one = g.Model.NewModelFromFile(os.path.join(res_dir, "one.uai"))
+    s1 = g.HIPChains.NewGibbsCollapsed(one, 64, 1)
+    with pytest.raises(g.GrError) as ei:
+        s1.Collapse(0, 0)
+    assert "0 variables" in str(ei.value)
+    od = g.Model.NewModelFromFile(os.path.join(res_dir, "ObjectDetection_13.uai"))
+    s2 = g.HIPChains.NewGibbsCollapsed(od, 64, 1)
+    big = [v for v in range(60) if s2.BlanketSize(0, v) >= 7]
+    with pytest.raises(g.GrError):
+        s2.Collapse(0, big[0])  # 16^6 entries > maxTabSize 2^23
+
+
+def test_merge_chains_semantics(res_dir):
+    """chain_test.go:11-80 TestMergeChains, on device-held counts: sums include each chain's 1/Card
+    prior; a variable collapsed in any group takes that group's exact marginal un-summed."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, "sample.uai"))  # cards 2,2,3
+    s = g.HIPChains.NewGibbsCollapsed(m, 128, 2)
+    v, marg = s.Collapse(1, 0)
+    assert v == 0
+    cnt = np.zeros((2, 7), dtype=np.uint64)
+    cnt[0] = [5, 7, 10, 20, 1, 2, 3]
+    cnt[1] = [0, 0, 30, 40, 4, 5, 6]
+    s.counts_upload(cnt)
+    merged, coll = g.MergeChains([s])
+    assert coll.tolist() == [1, 0, 0]
+    assert np.allclose(merged[0], marg)  # group 0's counts for var 0 are dropped
+    assert np.allclose(merged[1], [128 / 2 + 40, 128 / 2 + 60])
+    assert np.allclose(merged[2], [128 / 3 + 5, 128 / 3 + 7, 128 / 3 + 9])
+    with pytest.raises(g.GrError):
+        g.MergeChains([])
+    # two samplers (= two devices' worth), global variant order decides which exact marginal wins
+    t = g.HIPChains.NewGibbsCollapsed(m, 64, 1, variant_offset=2, chain_offset=128)
+    t.Collapse(0, 0)
+    t.counts_upload(np.array([[0, 0, 1, 1, 1, 1, 1]], dtype=np.uint64))
+    merged2, coll2 = g.MergeChains([t, s])
+    assert np.allclose(merged2[0], marg)
+    assert np.allclose(merged2[1], [192 / 2 + 41, 192 / 2 + 61])
+    assert g.allreduce_counts([s]).tolist() == cnt.tolist()  # single-device RCCL path is the identity
+
+
+def test_collapsed_sampling_matches_oracle(oracle, res_dir):
+    """BASELINE config 3 at oracle-sized scale: Segmentation_11, K variants each with a different
+    collapsed variable; GPU vs oracle chains built with the same collapsed variables."""
+    name = "Segmentation_11.uai"
+    pm = uai_py.load(res_dir, name)
+    sol = uai_py.load_mar(res_dir, name)
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    K, cpv = 16, 64
+    n = len(pm.card)
+    burn, upd = 10 * n, 30 * n
+
+    def gpu(seed, flags=0):
+        s = g.HIPChains.NewGibbsCollapsed(gm, K * cpv, K, seed=seed, flags=flags)
+        cv = []
+        for k in range(K):
+            v, _ = s.Collapse(k, -1)
+            cv.append(v)
+        s.BurnIn(burn); s.Advance(upd)
+        return s, cv
+
+    s, cv = gpu(42)
+    merged, coll = g.MergeChains([s])
+    cnt = s.counts()
+    off = np.concatenate([[0], np.cumsum(pm.card)])
+    for k, v in enumerate(cv):
+        assert cnt[k, off[v]:off[v + 1]].sum() == 0  # collapsed variable never sampled in its group
+        assert coll[v] == 1
+    assert int(cnt.sum()) == K * cpv * upd
+    # oracle: one chain per (variant, lane) is too slow; use 4 chains per variant with the same collapsed vars
+    per = 4
+    mo, ocoll, ocv, tot = oracle.run_chains(oracle.Model.from_parsed(pm), 42, K * per, burn, upd * 4, collapse_mode=2,
+                                            collapse_vars=[v for v in cv for _ in range(per)])
+    assert set(np.where(ocoll)[0]) == set(cv)
+    for v in set(cv):  # exact marginals agree (device f64 vs oracle f64)
+        assert np.allclose(merged[v] / merged[v].sum(), mo[v] / mo[v].sum(), rtol=1e-9)
+    s2, _ = gpu(43)
+    s3, _ = gpu(44)
+    H = lambda a, b: g.NewErrorSuite(pm.card, a, b)
+    m2, m3 = g.MergeChains([s2])[0], g.MergeChains([s3])[0]
+    # different seeds collapse different variables, so compare on error vs the exact solution
+    eo, e1, e2, e3 = (H(sol, x)["MeanHellinger"] for x in (mo, merged, m2, m3))
+    spread = max(abs(e1 - e2), abs(e1 - e3), abs(e2 - e3))
+    assert abs(e1 - eo) <= 3 * spread + 0.02, (eo, e1, e2, e3)
+    # memoised and direct paths agree bit for bit on collapsed models too
+    sd, cvd = gpu(42, g.GR_FLAG_DIRECT)
+    assert cvd == cv and np.array_equal(sd.counts(), cnt)

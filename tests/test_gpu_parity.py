@@ -1,0 +1,327 @@
+"""GPU parity tests (run with -m gpu on an MI355X).  Everything goes through the
+C ABI (include/grample_hip.h); the oracle (oracle/) is only the checker.
+
+Layers of evidence, strongest first:
+  1. conditional law: device conditional of (variable, state) == oracle's
+     GibbsSimple.SampleVar weights, entry by entry (deterministic);
+  2. process replay: an independent numpy emulator of the device process
+     (Philox streams, scan, threshold draws, counting) reproduces states and
+     counts BIT FOR BIT;
+  3. exact long-run law of the reference's chain on tiny models (transition
+     matrix built from oracle conditionals) vs GPU histograms;
+  4. statistical agreement with the oracle's own multi-chain runs and with
+     res/*.uai.MAR on the BASELINE models;
+  5. size-independent properties at full BASELINE sizes (determinism, chunk /
+     split independence, conservation, path equivalence).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import grample_amd as g
+from tests import exact_chain, uai_py
+from tests.emulator import Emulator
+
+pytestmark = pytest.mark.gpu
+
+
+def _gm(pm):
+    return g.Model.from_arrays(pm.card, pm.scopes, pm.tables, pm.fixed)
+
+
+def _norm(ms):
+    return [np.asarray(m, dtype=float) / np.sum(m) for m in ms]
+
+
+def _oracle_cond(oracle, samp, v, st, card):
+    p = np.zeros(card)
+    st = np.ascontiguousarray(st, dtype=np.int32)
+    rc = oracle.lib().orc_simple_conditional(samp, v, st.ctypes.data_as(C.POINTER(C.c_int)), p.ctypes.data_as(C.POINTER(C.c_double)))
+    assert rc == 0
+    return p
+
+
+# tolerance of a device conditional: thresholds are multiples of 2^-32 (abs 2.4e-10), log potentials and exp are f32
+COND_ABS, COND_REL = 4e-10, 5e-5
+
+
+# ------------------------------------------------------------ 1. conditionals
+@pytest.mark.parametrize("name,ev", [("one.uai", False), ("sample.uai", False), ("deterministic.uai", False),
+                                     ("Grids_11.uai", False), ("Grids_13.uai", False), ("Segmentation_11.uai", False),
+                                     ("ObjectDetection_13.uai", False), ("Promedus_11.uai", True),
+                                     ("Pedigree_11.uai", True), ("CSP_12.uai", False)])
+def test_conditional_matches_oracle(oracle, res_dir, name, ev):
+    """a4-a8: gather + log-sum + stabilise/exp/floor + normalise (gibbs-simple.go:175-258)."""
+    pm = uai_py.load(res_dir, name, ev)
+    L = oracle.lib()
+    om = oracle.Model.from_parsed(pm)
+    gen = L.orc_gen_new(1)
+    osamp = L.orc_simple_new(gen, om.ptr)
+    s = g.HIPChains.NewGibbsSimple(g.Model.NewModelFromFile(os.path.join(res_dir, name), ev), 64)
+    rng = np.random.default_rng(0)
+    free = [v for v in range(len(pm.card)) if pm.fixed[v] < 0]
+    hit_floor = 0
+    for _ in range(300):
+        st = np.array([rng.integers(0, c) if f < 0 else f for c, f in zip(pm.card, pm.fixed)], dtype=np.int32)
+        v = int(rng.choice(free))
+        pd = s.conditional(0, v, st)
+        po = _oracle_cond(oracle, osamp, v, st, pm.card[v])
+        assert abs(pd.sum() - 1.0) < 1e-12
+        assert np.all(np.abs(pd - po) <= COND_ABS + COND_REL * po), (name, v, pd, po)
+        hit_floor += int(po.min() < 2e-6)
+    if name == "Grids_13.uai":
+        assert hit_floor > 10  # the 1e-6 floor is exercised (tables span 5.5e-5 .. 1.8e4)
+    fx = [v for v in range(len(pm.card)) if pm.fixed[v] >= 0]
+    if fx:  # SampleVar on evidence is an error (gibbs-simple.go:167-169)
+        st = np.array([0 if f < 0 else f for f in pm.fixed], dtype=np.int32)
+        with pytest.raises(g.GrError):
+            s.conditional(0, fx[0], st)
+    L.orc_simple_free(osamp); L.orc_gen_free(gen)
+
+
+def test_conditional_exhaustive_tiny(oracle):
+    """Every (variable, state) of the tiny synthetic models, incl. table zeros and floored rows."""
+    import itertools
+    for name, pm in exact_chain.tiny_models().items():
+        L = oracle.lib()
+        om = oracle.Model.from_parsed(pm)
+        gen = L.orc_gen_new(1)
+        osamp = L.orc_simple_new(gen, om.ptr)
+        s = g.HIPChains.NewGibbsSimple(_gm(pm), 64)
+        ranges = [range(c) if f < 0 else [f] for c, f in zip(pm.card, pm.fixed)]
+        for st in itertools.islice(itertools.product(*ranges), 0, 600):
+            for v in range(len(pm.card)):
+                if pm.fixed[v] >= 0:
+                    continue
+                pd = s.conditional(0, v, list(st))
+                po = _oracle_cond(oracle, osamp, v, st, pm.card[v])
+                assert np.all(np.abs(pd - po) <= COND_ABS + COND_REL * po), (name, v, st, pd, po)
+        L.orc_simple_free(osamp); L.orc_gen_free(gen)
+
+
+# --------------------------------------------------------- 2. process replay
+def _thresholds_from_device(s, cards):
+    cache = {}
+
+    def thr(v, col):
+        key = (v, tuple(int(x) for x in col))
+        if key not in cache:
+            p = s.conditional(0, v, np.asarray(col, dtype=np.int32))
+            cache[key] = np.rint(np.cumsum(p)[:-1] * 4294967296.0).astype(np.uint64)
+        return cache[key]
+
+    return thr
+
+
+@pytest.mark.parametrize("name,ev,chains,steps,flags", [
+    ("Grids_11.uai", False, 128, 203, 0),
+    ("Grids_11.uai", False, 128, 203, g.GR_FLAG_DIRECT),
+    ("Grids_11.uai", False, 70, 57, g.GR_FLAG_SEQUENTIAL),  # ragged last wavefront
+    ("ObjectDetection_13.uai", False, 64, 41, 0),
+    ("Pedigree_11.uai", True, 64, 61, 0),
+    ("one.uai", False, 1, 64, 0),
+])
+def test_sweep_bitwise_vs_numpy_emulator(res_dir, name, ev, chains, steps, flags):
+    pm = uai_py.load(res_dir, name, ev)
+    off = 64 * 5 if chains % 64 == 0 else 0
+    s = g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, name), ev), chains, seed=1234, chain_offset=off, flags=flags)
+    free = [v for v in range(len(pm.card)) if pm.fixed[v] < 0]
+    em = Emulator(pm.card, pm.fixed, free, _thresholds_from_device(s, pm.card), chains, 1234, chain_offset=off)
+    for c in (0, chains - 1):  # start state (gibbs-simple.go:84-112)
+        assert np.array_equal(s.LastSample(c), em.state[:, c])
+    burn = 13
+    s.BurnIn(burn); em.run(burn, False)
+    a = steps // 2
+    s.Advance(a); s.Advance(steps - a)  # two launches, quad-unaligned boundary
+    em.run(steps, True)
+    assert np.array_equal(s.counts()[0], em.counts)
+    for c in range(chains):
+        assert np.array_equal(s.LastSample(c), em.state[:, c])
+    assert s.TotalSampleCount() == chains * steps
+    assert s.info()["step"] == burn + steps
+
+
+# ------------------------------------------- 3. exact long-run law, tiny models
+@pytest.mark.parametrize("model", ["sample.uai", "grid3x3", "mixed", "mixed_evidence"])
+@pytest.mark.parametrize("flags", [0, g.GR_FLAG_DIRECT])
+def test_histogram_converges_to_reference_chain_law(oracle, res_dir, model, flags):
+    pm = uai_py.load(res_dir, model) if model.endswith(".uai") else exact_chain.tiny_models()[model]
+    exp = exact_chain.expected_histogram(oracle, pm)
+    chains, burn, upd = 16384, 400, 6000
+    s = g.HIPChains(_gm(pm), chains, seed=99, flags=flags)
+    s.BurnIn(burn); s.Advance(upd)
+    cnt = s.counts()[0]
+    off = 0
+    for v, e in enumerate(exp):
+        c = cnt[off:off + pm.card[v]].astype(float)
+        off += pm.card[v]
+        if e is None:
+            assert c.sum() == 0  # evidence variables are never sampled
+            continue
+        # chains are independent; within a chain samples are correlated -> generous 6 sigma on an
+        # effective sample size of n/30, plus 1e-4 absolute.  Stated tolerance: |p_gpu - p_ref| <= tol.
+        n = c.sum()
+        p = c / n
+        tol = 6.0 * np.sqrt(np.maximum(e * (1 - e), 1e-6) / (n / 30.0)) + 1e-4
+        assert np.all(np.abs(p - e) <= tol), (model, v, p, e, tol)
+
+
+def test_one_uai_reference_config(oracle, res_dir):
+    """BASELINE config 0 / gibbs-simple_test.go:13-38: one.uai, 1 chain, 1k updates: both values occur;
+    many chains: histogram -> (0.25, 0.75) = one.uai.MAR."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, "one.uai"))
+    s = g.HIPChains.NewGibbsSimple(m, 1, seed=42)
+    seen = set()
+    for _ in range(64):
+        s.Advance(16)
+        seen.add(int(s.LastSample(0)[0]))
+    c = s.counts()[0]
+    assert c.sum() == 1024 and c[0] > 0 and c[1] > 0 and seen == {0, 1}
+    s2 = g.HIPChains.NewGibbsSimple(m, 4096, seed=42)
+    s2.Advance(1000)
+    merged, coll = g.MergeChains([s2])
+    sol = g.Solution.NewSolutionFromFile(os.path.join(res_dir, "one.uai.MAR")).marginals()
+    es = g.NewErrorSuite([2], sol, merged)
+    assert es["MaxHellinger"] < 1e-3 and es["MaxMeanAbsError"] < 1e-3
+    # Marginal = per-chain prior 1/Card + counts (variable.go:45, chain.go:230-236)
+    assert merged[0].sum() == pytest.approx(4096 * (1.0 + 1000), rel=1e-12)
+
+
+# ----------------------------------------- 4. statistical parity with the oracle
+def _group_props(counts, cards):
+    """counts [G, H] -> per-group value shares p[G, H] (each variable's block normalised)."""
+    G = counts.shape[0]
+    p = np.zeros(counts.shape)
+    off = 0
+    for c in cards:
+        blk = counts[:, off:off + c].astype(float)
+        p[:, off:off + c] = blk / np.maximum(blk.sum(axis=1, keepdims=True), 1.0)
+        off += c
+    return p
+
+
+@pytest.mark.parametrize("name,burn_sw,upd_sw,per", [("Grids_11.uai", 10, 30, 16), ("Segmentation_11.uai", 10, 30, 8),
+                                                     ("ObjectDetection_13.uai", 10, 40, 8)])
+def test_marginals_match_oracle_runs(oracle, res_dir, name, burn_sw, upd_sw, per):
+    """Two-sample test, oracle (MT19937-64, f64, Go semantics) vs GPU (Philox, f32 tables): same
+    burn-in and update counts per chain.  Both sides are run as G independent groups; a group's
+    histogram shares are i.i.d. across groups, so for every (variable, value)
+        z = (mean_oracle - mean_gpu) / sqrt(se_oracle^2 + se_gpu^2)
+    is ~N(0,1) if and only if the two samplers have the same law at that horizon (mixed or not).
+    Stated tolerance: max |z| <= 5.5 and mean z^2 <= 2 over all (variable, value) pairs."""
+    pm = uai_py.load(res_dir, name)
+    n = len(pm.card)
+    burn, upd = burn_sw * n, upd_sw * n
+    G = 32
+    s = g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, name)), G * 64, n_variants=G, seed=42)
+    s.BurnIn(burn); s.Advance(upd)
+    pg = _group_props(s.counts(), pm.card)
+    om = oracle.Model.from_parsed(pm)
+    prior = np.concatenate([np.full(c, per / c) for c in pm.card])
+    co = np.zeros((G, sum(pm.card)))
+    for grp in range(G):
+        mo, _, _, tot = oracle.run_chains(om, 1000 + grp, per, burn, upd)
+        assert tot == per * upd
+        co[grp] = np.concatenate(mo) - prior  # Marginal = 1/Card prior + counts (variable.go:45, chain.go:230-236)
+    assert np.all(co > -1e-6)
+    po = _group_props(np.rint(co), pm.card)
+    se = np.sqrt(po.var(axis=0, ddof=1) / G + pg.var(axis=0, ddof=1) / G)
+    z = (po.mean(axis=0) - pg.mean(axis=0)) / np.maximum(se, 2e-4)
+    assert np.max(np.abs(z)) <= 5.5, (name, np.max(np.abs(z)), np.argmax(np.abs(z)))
+    assert np.mean(z ** 2) <= 2.0, (name, np.mean(z ** 2))
+    # and the headline metric agrees: Hellinger vs res/<model>.uai.MAR is the same for both
+    sol = uai_py.load_mar(res_dir, name)
+    split = lambda flat: g.split(flat, pm.card)
+    eo = g.NewErrorSuite(pm.card, sol, split(po.mean(axis=0) + 1e-12))
+    eg = g.NewErrorSuite(pm.card, sol, split(pg.mean(axis=0) + 1e-12))
+    assert abs(eo["MeanHellinger"] - eg["MeanHellinger"]) <= 0.02, (eo, eg)
+
+
+def test_objectdetection_reaches_mar(res_dir):
+    """ObjectDetection_13 mixes (slowly): with long chains the GPU estimate approaches the exact .MAR."""
+    name = "ObjectDetection_13.uai"
+    pm = uai_py.load(res_dir, name)
+    sol = uai_py.load_mar(res_dir, name)
+    s = g.HIPChains.NewGibbsSimple(g.Model.NewModelFromFile(os.path.join(res_dir, name)), 1024, seed=42)
+    s.BurnIn(60 * 1000); s.Advance(60 * 3000)
+    es = g.NewErrorSuite(pm.card, sol, g.MergeChains([s])[0])
+    assert es["MeanHellinger"] < 0.02 and es["MaxHellinger"] < 0.08, es
+
+
+# ----------------------------------------------- 5. properties at BASELINE sizes
+@pytest.mark.parametrize("name,chains", [("Grids_13.uai", 65536), ("Grids_11.uai", 4096), ("ObjectDetection_13.uai", 32768)])
+def test_full_size_properties(res_dir, name, chains):
+    path = os.path.join(res_dir, name)
+    m = g.Model.NewModelFromFile(path)
+    n = m.n_vars
+    upd = 8 * n + 3
+
+    def run(chunks, flags=0, **kw):
+        s = g.HIPChains.NewGibbsSimple(m, chains, seed=7, flags=flags, **kw)
+        s.BurnIn(2 * n + 1)
+        for c in chunks:
+            s.Advance(c)
+        return s
+
+    a = run([upd])
+    ca = a.counts()[0]
+    assert int(ca.sum()) == chains * upd == a.TotalSampleCount()  # conservation
+    assert np.array_equal(ca, run([upd]).counts()[0])  # determinism
+    assert np.array_equal(ca, run([5, upd - 5 - 2 * n, 2 * n]).counts()[0])  # launch chunking
+    assert np.array_equal(ca, run([upd], g.GR_FLAG_SEQUENTIAL).counts()[0])  # co-issue == sequential
+    assert np.array_equal(ca, run([upd], g.GR_FLAG_DIRECT).counts()[0])  # memoised == direct
+    assert np.array_equal(ca, run([upd], block_threads=64).counts()[0])  # block shape
+    # the split of the chains over devices does not change the result
+    h = chains // 2
+    parts = []
+    for k in range(2):
+        s = g.HIPChains.NewGibbsSimple(m, h, seed=7, chain_offset=k * h)
+        s.BurnIn(2 * n + 1); s.Advance(upd)
+        parts.append(s)
+    assert np.array_equal(ca, parts[0].counts()[0] + parts[1].counts()[0])
+    assert np.array_equal(a.LastSample(h + 5), parts[1].LastSample(5))
+    merged, _ = g.MergeChains(parts)
+    whole, _ = g.MergeChains([a])
+    assert all(np.allclose(x, y, rtol=1e-15) for x, y in zip(merged, whole))
+    # every free variable keeps both/all values reachable (floor) and counts are per-variable consistent
+    cards = m.cards()
+    off = 0
+    for v in range(n):
+        assert ca[off:off + cards[v]].sum() % 1 == 0
+        off += cards[v]
+
+
+def test_evidence_variables_never_change(res_dir):
+    """a2/a13: evidence variables start at FixedVal, are never selected, never counted."""
+    name = "Promedus_11.uai"
+    pm = uai_py.load(res_dir, name, True)
+    s = g.HIPChains.NewGibbsSimple(g.Model.NewModelFromFile(os.path.join(res_dir, name), True), 256, seed=3)
+    s.BurnIn(1000); s.Advance(5000)
+    cnt = s.counts()[0]
+    st = s.LastSample(17)
+    off = 0
+    for v, (c, f) in enumerate(zip(pm.card, pm.fixed)):
+        if f >= 0:
+            assert st[v] == f and cnt[off:off + c].sum() == 0
+        off += c
+    sol = uai_py.load_mar(res_dir, name)
+    merged, _ = g.MergeChains([s])
+    es = g.NewErrorSuite(pm.card, sol, merged, fixed1=pm.fixed)
+    assert es["MeanHellinger"] < 0.3  # sanity only: Promedus mixes slowly
+
+
+def test_state_roundtrip_and_errors(res_dir):
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, "sample.uai"))
+    s = g.HIPChains.NewGibbsSimple(m, 64)
+    s.set_state(3, [1, 0, 2])
+    assert s.LastSample(3).tolist() == [1, 0, 2]
+    with pytest.raises(g.GrError):
+        s.set_state(3, [1, 0, 3])
+    with pytest.raises(g.GrError):
+        s.LastSample(64)
+    with pytest.raises(g.GrError):
+        g.HIPChains(m, 100, n_variants=3)
+    with pytest.raises(g.GrError):
+        g.HIPChains(m, 64, chain_offset=5)
