@@ -10,11 +10,15 @@ OBJDIR := build/obj
 # way in all three.
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-result
 LIB := grample_amd/libgrample_hip.so
-OBJS := $(OBJDIR)/kernels.o $(OBJDIR)/sampler.o $(OBJDIR)/host_model.o $(OBJDIR)/compiled_model.o
+OBJS := $(OBJDIR)/kernels.o $(OBJDIR)/sweep_bin.o $(OBJDIR)/sampler.o $(OBJDIR)/host_model.o $(OBJDIR)/compiled_model.o
 
 all: $(LIB) oracle
 
 $(OBJDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJDIR)/sweep_bin.o: $(CSRC)/sweep_bin.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

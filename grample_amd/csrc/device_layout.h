@@ -16,7 +16,8 @@ struct VariantDesc {
     uint32_t cprogoff_base;// entries, into cprog_off
     uint32_t cpt_base;     // words, into cpt
     uint32_t cpt_len;      // words
-    uint32_t pad0, pad1;
+    uint32_t rec_base;     // records (kRecDwords each), into recs: one per entry of this group's free list
+    uint32_t pad1;
 };
 
 struct SweepParams {
@@ -43,6 +44,35 @@ struct SweepParams {
     uint32_t sequential;        // 1 = never co-issue commuting updates
     uint32_t lds_hist_off;      // byte offsets inside dynamic LDS
     uint32_t lds_tab_off;
+};
+
+// Fast binary/memoised path (sweep_bin.hip).  A RECORD is one 64-byte line per
+// selectable variable:
+//   w0 state-row byte offset (var * T)      w1 histogram byte offset (4 * offset of value 0)
+//   w2 LDS byte offset of the variable's threshold table     w3 number of neighbours
+//   unpacked (<= 6 neighbours): w[4+2i] neighbour state-row byte offset, w[5+2i] 4 * mixed-radix multiplier
+//   packed (7..12 neighbours):  w[4+i]  = row offset | (4 * multiplier) << 16
+// padding slots point at the variable's own row with multiplier 0.
+constexpr uint32_t kRecDwords = 16;
+
+struct FastParams {
+    const VariantDesc *variants;
+    const uint32_t *free_vars;
+    const uint32_t *cprogs;
+    const uint32_t *cprog_off;
+    const uint32_t *cpt;
+    const uint32_t *recs;
+    uint32_t *plan;             // [n_chains/64][plan_pitch] u32, written by k_scan_plan
+    unsigned char *state;
+    unsigned long long *counts;
+    uint32_t plan_pitch;        // words per wavefront row (multiple of 4)
+    uint32_t n_vars, H, n_chains, pitch, chains_per_variant;
+    uint32_t chain_offset_lo, chain_offset_hi;
+    uint32_t seed_lo, seed_hi;
+    uint32_t step0_lo, step0_hi; // multiple of 4
+    uint32_t n_steps;            // multiple of 4
+    uint32_t counting;
+    uint32_t lds_hist_off, lds_tab_off;
 };
 
 } // namespace gr

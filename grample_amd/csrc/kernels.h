@@ -36,5 +36,8 @@ hipError_t launch_build_cpt(const VariantDesc &vd, const uint32_t *progs, const 
 hipError_t launch_conditional(const VariantDesc &vd, const uint32_t *progs, const uint32_t *prog_off, const float *views,
                               uint32_t v, const int32_t *state, double *probs, int max_card, hipStream_t s);
 hipError_t launch_collapse(const CollapseArgs &a, uint32_t blocks, hipStream_t s);
+// fast binary / memoised path (sweep_bin.hip)
+hipError_t launch_scan_plan(const FastParams &p, hipStream_t s);
+hipError_t launch_sweep_bin(const FastParams &p, int slots, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s);
 
 } // namespace gr

@@ -97,6 +97,10 @@ struct gr_sampler {
     // configuration
     uint32_t T = 0, blocks = 0, lds = 0, lds_hist_off = 0, lds_tab_off = 0, pitch = 0, cpv = 0;
     bool cpt = false, tab_lds = false;
+    bool fast = false;                // binary + memoised + whole wavefronts: sweep_bin.hip
+    int fast_slots = 0;               // max neighbours of any selectable variable
+    uint32_t plan_steps = 0;          // steps per fast launch (plan row length)
+    DevBuf<uint32_t> d_recs, d_plan;
     // device pools
     DevBuf<VariantDesc> d_variants;
     DevBuf<uint32_t> d_progs, d_prog_off, d_free, d_cprogs, d_cprog_off, d_cpt;
@@ -143,11 +147,24 @@ void gr_sampler::configure() {
         if (tl) b += (use_cpt ? cpt_max : views_max) * 4u;
         return b;
     };
+    // fast path (sweep_bin.hip): every selectable variable binary, memoised tables, whole wavefronts
+    bool fast_ok = all_cpt && !(o.flags & GR_FLAG_SEQUENTIAL) && (o.n_chains % 64u) == 0 && n_vars < 65536 && H < 16384;
+    int slots = 0;
+    if (fast_ok)
+        for (uint32_t g = 0; g < o.n_variants && fast_ok; ++g)
+            for (uint32_t v : image[g].free_vars) {
+                const uint32_t *cp = image[g].cprog.data() + image[g].cprog_off[v];
+                if ((cp[0] & 0xffu) != 2u) { fast_ok = false; break; }
+                slots = std::max<int>(slots, (int)((cp[0] >> 8) & 0xffu));
+            }
+    if (slots > 12) fast_ok = false;
     std::vector<uint32_t> cands;
     if (o.block_threads) {
-        if (o.block_threads != 64 && o.block_threads != 128 && o.block_threads != 256)
-            throw Error(GR_E_INVALID, "block_threads must be 0, 64, 128 or 256");
-        cands = {o.block_threads};
+        const uint32_t bt = o.block_threads;
+        if (bt != 64 && bt != 128 && bt != 256 && bt != 512 && bt != 1024)
+            throw Error(GR_E_INVALID, "block_threads must be 0, 64, 128, 256, 512 or 1024");
+        if (bt > 256 && !fast_ok) throw Error(GR_E_INVALID, "block_threads > 256 needs the binary memoised path");
+        cands = {bt};
     } else {
         // 256-lane blocks share one staged table copy between 4 waves; use them once
         // every CU gets a block anyway, otherwise spread single-wave blocks.
@@ -166,6 +183,10 @@ void gr_sampler::configure() {
                 if (b > kLdsBudget) continue;
                 T = t; lds = b; lds_hist_off = ho; lds_tab_off = to; cpt = use_cpt; tab_lds = tl;
                 blocks = (o.n_chains + T - 1) / T;
+                fast = fast_ok && use_cpt && tl && (o.n_chains % T) == 0;
+                if (fast && slots > 6 && ((uint64_t)n_vars * T >= 65536u || cpt_max * 4u >= 65536u)) fast = false; // packed slots are 16+16 bit
+                fast_slots = slots;
+                if (T > 256 && !fast) continue;
                 return;
             }
         }
@@ -217,6 +238,36 @@ void gr_sampler::rebuild() {
             hip_check(launch_build_cpt(h_variants[g], d_progs.p, d_prog_off.p, d_views.p, d_cprogs.p, d_cprog_off.p, d_cpt.p,
                                        d_card.p, d_fixed.p, (uint32_t)n_vars, std::max(1u, image[g].max_cfg), max_card, stream),
                       "k_build_cpt");
+    if (fast) {
+        std::vector<uint32_t> recs;
+        for (uint32_t g = 0; g < o.n_variants; ++g) {
+            const VariantImage &im = image[g];
+            h_variants[g].rec_base = (uint32_t)(recs.size() / kRecDwords);
+            for (uint32_t v : im.free_vars) {
+                const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
+                const uint32_t nn = (cp[0] >> 8) & 0xffu;
+                uint32_t r[kRecDwords] = {0};
+                r[0] = v * T;
+                r[1] = cp[1] * 4u;
+                r[2] = lds_tab_off + cp[2] * 4u;
+                r[3] = nn;
+                const bool packed = fast_slots > 6;
+                for (uint32_t i = 0; i < (packed ? 12u : 6u); ++i) {
+                    const uint32_t off = (i < nn ? cp[3 + 2 * i] : v) * T, m4 = (i < nn ? cp[4 + 2 * i] : 0u) * 4u;
+                    if (packed) r[4 + i] = off | (m4 << 16);
+                    else { r[4 + 2 * i] = off; r[5 + 2 * i] = m4; }
+                }
+                recs.insert(recs.end(), r, r + kRecDwords);
+            }
+        }
+        d_variants.upload(h_variants, stream); // now with rec_base
+        d_recs.upload(recs, stream);
+        const uint64_t waves = o.n_chains / 64u;
+        uint64_t ps = (64ull << 20) / (waves * 4ull); // <= 64 MiB of plan per launch
+        ps = std::min<uint64_t>(ps, kMaxStepsPerLaunch) & ~3ull;
+        plan_steps = (uint32_t)std::max<uint64_t>(ps, 4);
+        d_plan.alloc((size_t)waves * plan_steps + 16);
+    }
     sync();
     dirty = false;
 }
@@ -249,15 +300,53 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     p.sequential = (o.flags & GR_FLAG_SEQUENTIAL) ? 1u : 0u;
     p.lds_hist_off = lds_hist_off; p.lds_tab_off = lds_tab_off;
     hip_check(hipEventRecord(ev0, stream), "hipEventRecord");
-    uint64_t left = updates;
-    while (left) {
-        const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
-        p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
-        p.n_steps = n;
-        hip_check(launch_sweep(p, max_card, cpt, tab_lds, blocks, T, lds, stream), "k_sweep launch");
-        step += n;
-        left -= n;
-        launches_last++;
+    auto generic = [&](uint64_t n_total) {
+        uint64_t left = n_total;
+        while (left) {
+            const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
+            p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
+            p.n_steps = n;
+            hip_check(launch_sweep(p, max_card, cpt, tab_lds, blocks, T, lds, stream), "k_sweep launch");
+            step += n;
+            left -= n;
+            launches_last++;
+        }
+    };
+    // the generic kernel on the fast path's geometry: same LDS layout (state stride = block size), <= 256 lanes
+    auto generic_small = [&](uint64_t n_total) {
+        if (T <= 256) { generic(n_total); return; }
+        // blocks of 256 lanes: the layout offsets were sized for T lanes, which is larger -> still fits
+        const uint32_t keepT = T, keepB = blocks;
+        T = 256; blocks = (o.n_chains + 255) / 256;
+        generic(n_total);
+        T = keepT; blocks = keepB;
+    };
+    if (!fast) {
+        generic(updates);
+    } else {
+        // quad-unaligned head and tail go through the generic kernel (bit-identical streams)
+        FastParams f{};
+        f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p;
+        f.cpt = d_cpt.p; f.recs = d_recs.p; f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p;
+        f.plan_pitch = plan_steps;
+        f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = o.n_chains; f.pitch = pitch; f.chains_per_variant = cpv;
+        f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
+        f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi;
+        f.counting = p.counting; f.lds_hist_off = lds_hist_off; f.lds_tab_off = lds_tab_off;
+        uint64_t left = updates;
+        const uint64_t head = std::min<uint64_t>(left, (4 - (step & 3)) & 3);
+        if (head) { generic_small(head); left -= head; }
+        while (left >= 4) {
+            const uint32_t n = (uint32_t)std::min<uint64_t>(left & ~3ull, plan_steps);
+            f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
+            f.n_steps = n;
+            hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
+            hip_check(launch_sweep_bin(f, fast_slots, blocks, T, lds, stream), "k_sweep_bin launch");
+            step += n;
+            left -= n;
+            launches_last++;
+        }
+        if (left) generic_small(left);
     }
     hip_check(hipEventRecord(ev1, stream), "hipEventRecord");
     sync();
@@ -789,7 +878,7 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         if (!s || !out || out->struct_size != sizeof(gr_sampler_info)) throw Error(GR_E_INVALID, "bad gr_sampler_info");
         if (s->dirty) { s->use(); s->configure(); }
         out->block_threads = s->T; out->n_blocks = s->blocks; out->lds_bytes = s->lds;
-        out->path = s->cpt ? 1u : 0u; out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
+        out->path = s->fast ? 2u : (s->cpt ? 1u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

@@ -181,7 +181,7 @@ typedef struct gr_sampler_info {
     uint32_t block_threads;
     uint32_t n_blocks;
     uint32_t lds_bytes;
-    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables */
+    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path) */
     uint32_t max_card;
     uint32_t tables_in_lds;
     uint32_t n_launches_last;
