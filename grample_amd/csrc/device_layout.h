@@ -73,6 +73,7 @@ struct FastParams {
     uint32_t n_steps;            // multiple of 4
     uint32_t counting;
     uint32_t lds_hist_off, lds_tab_off;
+    uint32_t lds_plan_off;       // per-wave plan ring: 2 x 64 quads x 16 B
 };
 
 } // namespace gr

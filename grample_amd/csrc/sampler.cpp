@@ -95,7 +95,7 @@ struct gr_sampler {
     bool dirty = true;                // device pools need rebuilding
     bool started = false;             // any burn-in / advance done
     // configuration
-    uint32_t T = 0, blocks = 0, lds = 0, lds_hist_off = 0, lds_tab_off = 0, pitch = 0, cpv = 0;
+    uint32_t T = 0, blocks = 0, lds = 0, lds_hist_off = 0, lds_tab_off = 0, lds_plan_off = 0, pitch = 0, cpv = 0;
     bool cpt = false, tab_lds = false;
     bool fast = false;                // binary + memoised + whole wavefronts: sweep_bin.hip
     int fast_slots = 0;               // max neighbours of any selectable variable
@@ -137,6 +137,7 @@ void gr_sampler::configure() {
         cpt_max = std::max<uint32_t>(cpt_max, (im.cpt_words + 3u) & ~3u);
         all_cpt = all_cpt && im.cpt_ok;
     }
+    uint32_t plan_off = 0;
     auto layout = [&](uint32_t t, bool use_cpt, bool tl, uint32_t &hist_off, uint32_t &tab_off) -> uint32_t {
         uint32_t b = (uint32_t)n_vars * t;
         b = (b + 15u) & ~15u;
@@ -145,6 +146,9 @@ void gr_sampler::configure() {
         b = (b + 15u) & ~15u;
         tab_off = b;
         if (tl) b += (use_cpt ? cpt_max : views_max) * 4u;
+        b = (b + 15u) & ~15u;
+        plan_off = b;
+        if (use_cpt && tl) b += (t / 64u) * 2048u; // fast path: per-wave scan-plan ring
         return b;
     };
     // fast path (sweep_bin.hip): every selectable variable binary, memoised tables, whole wavefronts
@@ -181,7 +185,7 @@ void gr_sampler::configure() {
                 uint32_t ho, to;
                 const uint32_t b = layout(t, use_cpt, tl, ho, to);
                 if (b > kLdsBudget) continue;
-                T = t; lds = b; lds_hist_off = ho; lds_tab_off = to; cpt = use_cpt; tab_lds = tl;
+                T = t; lds = b; lds_hist_off = ho; lds_tab_off = to; lds_plan_off = plan_off; cpt = use_cpt; tab_lds = tl;
                 blocks = (o.n_chains + T - 1) / T;
                 fast = fast_ok && use_cpt && tl && (o.n_chains % T) == 0;
                 if (fast && slots > 6 && ((uint64_t)n_vars * T >= 65536u || cpt_max * 4u >= 65536u)) fast = false; // packed slots are 16+16 bit
@@ -332,7 +336,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = o.n_chains; f.pitch = pitch; f.chains_per_variant = cpv;
         f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
         f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi;
-        f.counting = p.counting; f.lds_hist_off = lds_hist_off; f.lds_tab_off = lds_tab_off;
+        f.counting = p.counting; f.lds_hist_off = lds_hist_off; f.lds_tab_off = lds_tab_off; f.lds_plan_off = lds_plan_off;
         uint64_t left = updates;
         const uint64_t head = std::min<uint64_t>(left, (4 - (step & 3)) & 3);
         if (head) { generic_small(head); left -= head; }

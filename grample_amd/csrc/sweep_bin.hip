@@ -66,31 +66,63 @@ struct Rec {
     uint32_t w[kRecDwords];
 };
 
+// Records are read-only for the whole launch: load them through the constant address space so
+// that a uniform address always becomes a scalar (s_load) access served by the scalar cache.
+typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
 __device__ __forceinline__ void load_rec(Rec &r, const uint32_t *recs, uint32_t plan_word) {
-    const uint32_t *rp = reinterpret_cast<const uint32_t *>(
-        __builtin_assume_aligned(reinterpret_cast<const unsigned char *>(recs) + (plan_word & ~1u), 64));
+    const_u32_ptr rp = (const_u32_ptr)(uintptr_t)(reinterpret_cast<const unsigned char *>(recs) + (plan_word & ~1u));
 #pragma unroll
     for (int i = 0; i < kRecDwords; ++i) r.w[i] = rp[i];
 }
 
+// Philox4x32-10 with the rounds exposed, so that groups of rounds can be placed
+// where the kernel has latency to hide (same arithmetic as philox4x32_10()).
+struct PhiloxSteps {
+    uint32_t c0, c1, c2, c3, k0, k1;
+    template <int N>
+    __device__ __forceinline__ void rounds() {
+#pragma unroll
+        for (int r = 0; r < N; ++r) {
+            const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
+            const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
+            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+            const uint32_t n1 = (uint32_t)p1;
+            const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+            const uint32_t n3 = (uint32_t)p0;
+            c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+            k0 += PHILOX_W0;
+            k1 += PHILOX_W1;
+        }
+    }
+};
+
+// gathers the blanket configuration of one step: issues the neighbour-state reads
 template <int SLOTS, bool PACKED>
-__device__ __forceinline__ uint32_t sample_rec(const Rec &r, const unsigned char *lds_tid, const unsigned char *lds, const uint32_t u) {
+__device__ __forceinline__ void read_states(const Rec &r, const unsigned char *lds_tid, uint32_t (&x)[SLOTS]) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const uint32_t off = PACKED ? (r.w[4 + i] & 0xffffu) : r.w[4 + 2 * i];
+        x[i] = (uint32_t)lds_tid[off];
+    }
+}
+template <int SLOTS, bool PACKED>
+__device__ __forceinline__ uint32_t table_word(const Rec &r, const uint32_t (&x)[SLOTS], const unsigned char *lds) {
     uint32_t cfg4 = 0;
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
-        uint32_t off, m4;
-        if constexpr (PACKED) {
-            off = r.w[4 + i] & 0xffffu;
-            m4 = r.w[4 + i] >> 16;
-        } else {
-            off = r.w[4 + 2 * i];
-            m4 = r.w[5 + 2 * i];
-        }
-        cfg4 += __umul24(m4, (uint32_t)lds_tid[off]);
+        const uint32_t m4 = PACKED ? (r.w[4 + i] >> 16) : r.w[5 + 2 * i];
+        cfg4 += __umul24(m4, x[i]);
     }
-    const uint32_t T = *reinterpret_cast<const uint32_t *>(lds + r.w[2] + cfg4);
-    return (u >= T) ? 1u : 0u;
+    return *reinterpret_cast<const uint32_t *>(lds + r.w[2] + cfg4);
 }
+template <int SLOTS, bool PACKED>
+__device__ __forceinline__ uint32_t sample_rec(const Rec &r, const unsigned char *lds_tid, const unsigned char *lds, const uint32_t u) {
+    uint32_t x[SLOTS];
+    read_states<SLOTS, PACKED>(r, lds_tid, x);
+    return (u >= table_word<SLOTS, PACKED>(r, x, lds)) ? 1u : 0u;
+}
+
+constexpr uint32_t kPlanChunk = 64; // quads per staged plan chunk; the LDS ring holds two chunks per wave
 
 template <int SLOTS, bool PACKED, bool COUNT>
 __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
@@ -119,23 +151,42 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
     const uint32_t hist_base = uni_b(p.lds_hist_off + wave * p.H * 4u); // LDS byte offset of this wave's histogram
     const uint64_t q0 = (((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2;
     const uint32_t nq = p.n_steps >> 2;
-    const uint4 *plan = reinterpret_cast<const uint4 *>(p.plan + (size_t)wave_local * p.plan_pitch);
     // lanes 0/1 carry the (zeros, ones) histogram increments: d = sign * ones + base
     const int h_sign = lane == 0 ? -1 : 1;
     const int h_base = lane == 0 ? 64 : 0;
-    const uint32_t h_lane = lane * 4u;
+    const uint32_t h_addr = hist_base + lane * 4u;
 
-    uint4 P = plan[0];
+    // ---- the wave's scan plan, staged through a private LDS ring of 2 x 64 quads.  Lane l of the
+    // wave carries quad (chunk * 64 + l); one global_load_dwordx4 + one ds_write_b128 per 64 quads.
+    // Vector loads on purpose: vmcnt is separate from the LDS/scalar counter and in order, so a
+    // chunk prefetched half a chunk ahead never stalls an LDS wait.
+    const uint4 *gplan = reinterpret_cast<const uint4 *>(p.plan + (size_t)wave_local * p.plan_pitch);
+    uint4 *ring = reinterpret_cast<uint4 *>(lds + p.lds_plan_off + wave * (2u * kPlanChunk * 16u));
+    const uint32_t nchunks = (nq + kPlanChunk - 1) / kPlanChunk;
+    auto gload = [&](uint32_t chunk) -> uint4 {
+        const uint32_t i = chunk * kPlanChunk + lane;
+        return gplan[i < nq ? i : nq - 1];
+    };
+    ring[lane] = gload(0);
+    uint4 stage = gload(nchunks > 1 ? 1 : 0);
+    auto ring_read = [&](uint32_t g) -> uint4 { return ring[(g < nq ? g : nq - 1) & (2u * kPlanChunk - 1u)]; };
+
     Rec R0, R1, R2, R3;
-    load_rec(R0, p.recs, P.x); load_rec(R1, p.recs, P.y); load_rec(R2, p.recs, P.z); load_rec(R3, p.recs, P.w);
-    uint4 Pn = plan[nq > 1 ? 1 : 0];
+    uint32_t flags;
+    {
+        const uint4 P0 = ring_read(0);
+        const uint32_t a = uni_b(P0.x), b = uni_b(P0.y), c = uni_b(P0.z), d = uni_b(P0.w);
+        load_rec(R0, p.recs, a); load_rec(R1, p.recs, b); load_rec(R2, p.recs, c); load_rec(R3, p.recs, d);
+        flags = (b & 1u) | ((c & 1u) << 1) | ((d & 1u) << 2);
+    }
+    uint4 PV = ring_read(1); // plan of the NEXT quad, as uniform VGPRs
 
     auto commit = [&](const Rec &r, const uint32_t val) {
         st[r.w[0]] = (unsigned char)val;
         if constexpr (COUNT) {
             const uint32_t ones = (uint32_t)__popcll(__ballot(val != 0));
             if (lane < 2) {
-                uint32_t *hp = reinterpret_cast<uint32_t *>(lds + hist_base + r.w[1] + h_lane);
+                uint32_t *hp = reinterpret_cast<uint32_t *>(lds + h_addr + r.w[1]);
                 __hip_atomic_fetch_add(hp, (uint32_t)(h_sign * (int)ones + h_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
@@ -143,31 +194,52 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
 
     for (uint32_t qi = 0; qi < nq; ++qi) {
         const uint64_t q = q0 + qi;
-        const u32x4 dr = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain,
-                                       DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
-        // the draw-stream Philox (pure VALU) is issued BEFORE the first use of the prefetched records:
-        // it is what hides their scalar-load latency
+        if ((qi & (kPlanChunk - 1u)) == kPlanChunk / 2u) {
+            // mid-chunk: park the prefetched next chunk in the other half of the ring, fetch the one after it
+            const uint32_t nc = qi / kPlanChunk + 1u;
+            if (nc < nchunks) {
+                ring[(nc & 1u) * kPlanChunk + lane] = stage;
+                if (nc + 1u < nchunks) stage = gload(nc + 1u);
+            }
+        }
+        PhiloxSteps ph{(uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi};
+        // rounds 1-4 cover what is left of the record loads' scalar-cache latency (issued at the end of the previous quad)
+        ph.rounds<4>();
         __builtin_amdgcn_sched_barrier(0);
-        const uint32_t c1 = P.y & 1u, c2 = P.z & 1u, c3 = P.w & 1u;
-        // phase A: all four conditionals from the current state
-        uint32_t v0 = sample_rec<SLOTS, PACKED>(R0, st, lds, dr.x);
-        uint32_t v1 = sample_rec<SLOTS, PACKED>(R1, st, lds, dr.y);
-        uint32_t v2 = sample_rec<SLOTS, PACKED>(R2, st, lds, dr.z);
-        uint32_t v3 = sample_rec<SLOTS, PACKED>(R3, st, lds, dr.w);
-        // phase B: commit in order; recompute a step that reads what an earlier step of the quad wrote
-        commit(R0, v0);
-        if (c1) v1 = sample_rec<SLOTS, PACKED>(R1, st, lds, dr.y);
-        commit(R1, v1);
-        if (c2) v2 = sample_rec<SLOTS, PACKED>(R2, st, lds, dr.z);
-        commit(R2, v2);
-        if (c3) v3 = sample_rec<SLOTS, PACKED>(R3, st, lds, dr.w);
-        commit(R3, v3);
-        // fetch the next quad's records (and the plan one further ahead): in flight across the back edge,
-        // hidden by the next iteration's draw-stream Philox
+        uint32_t x0[SLOTS], x1[SLOTS], x2[SLOTS], x3[SLOTS];
+        read_states<SLOTS, PACKED>(R0, st, x0);
+        read_states<SLOTS, PACKED>(R1, st, x1);
+        read_states<SLOTS, PACKED>(R2, st, x2);
+        read_states<SLOTS, PACKED>(R3, st, x3);
         __builtin_amdgcn_sched_barrier(0);
-        P = Pn;
-        load_rec(R0, p.recs, P.x); load_rec(R1, p.recs, P.y); load_rec(R2, p.recs, P.z); load_rec(R3, p.recs, P.w);
-        Pn = plan[(qi + 2 < nq) ? qi + 2 : qi];
+        ph.rounds<4>(); // rounds 5-8 cover the state reads
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t t0 = table_word<SLOTS, PACKED>(R0, x0, lds);
+        const uint32_t t1 = table_word<SLOTS, PACKED>(R1, x1, lds);
+        const uint32_t t2 = table_word<SLOTS, PACKED>(R2, x2, lds);
+        const uint32_t t3 = table_word<SLOTS, PACKED>(R3, x3, lds);
+        __builtin_amdgcn_sched_barrier(0);
+        ph.rounds<2>(); // rounds 9-10 cover the table reads
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t v0 = ph.c0 >= t0, v1 = ph.c1 >= t1, v2 = ph.c2 >= t2, v3 = ph.c3 >= t3;
+        // commit in order; a step that reads what an earlier step of the quad wrote is recomputed first
+        if (flags == 0) {
+            commit(R0, v0); commit(R1, v1); commit(R2, v2); commit(R3, v3);
+        } else {
+            commit(R0, v0);
+            if (flags & 1u) v1 = sample_rec<SLOTS, PACKED>(R1, st, lds, ph.c1);
+            commit(R1, v1);
+            if (flags & 2u) v2 = sample_rec<SLOTS, PACKED>(R2, st, lds, ph.c2);
+            commit(R2, v2);
+            if (flags & 4u) v3 = sample_rec<SLOTS, PACKED>(R3, st, lds, ph.c3);
+            commit(R3, v3);
+        }
+        // next quad: plan words -> SGPRs -> record loads (scalar cache), then the plan of the quad after it
+        __builtin_amdgcn_sched_barrier(0);
+        const uint32_t a = uni_b(PV.x), b = uni_b(PV.y), c = uni_b(PV.z), d = uni_b(PV.w);
+        load_rec(R0, p.recs, a); load_rec(R1, p.recs, b); load_rec(R2, p.recs, c); load_rec(R3, p.recs, d);
+        flags = (b & 1u) | ((c & 1u) << 1) | ((d & 1u) << 2);
+        PV = ring_read(qi + 2u);
     }
 
     for (uint32_t vv = 0; vv < p.n_vars; ++vv) p.state[(size_t)vv * p.pitch + chain] = st[vv * T];
