@@ -74,6 +74,9 @@ struct FastParams {
     uint32_t counting;
     uint32_t lds_hist_off, lds_tab_off;
     uint32_t lds_plan_off;       // per-wave plan ring: 2 x 64 quads x 16 B
+    // step-parallel form (k_sweep_par4): its own records (80-byte state rows) and LDS layout
+    const uint32_t *recs_par;
+    uint32_t par_hist_off, par_tab_off, par_rec_off, par_plan_off, par_scr_off;
 };
 
 } // namespace gr

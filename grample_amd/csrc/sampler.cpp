@@ -100,7 +100,9 @@ struct gr_sampler {
     bool fast = false;                // binary + memoised + whole wavefronts: sweep_bin.hip
     int fast_slots = 0;               // max neighbours of any selectable variable
     uint32_t plan_steps = 0;          // steps per fast launch (plan row length)
-    DevBuf<uint32_t> d_recs, d_plan;
+    DevBuf<uint32_t> d_recs, d_plan, d_recs_par;
+    bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
+    uint32_t par_hist_off = 0, par_tab_off = 0, par_rec_off = 0, par_plan_off = 0, par_scr_off = 0, par_lds = 0;
     // device pools
     DevBuf<VariantDesc> d_variants;
     DevBuf<uint32_t> d_progs, d_prog_off, d_free, d_cprogs, d_cprog_off, d_cpt;
@@ -191,6 +193,21 @@ void gr_sampler::configure() {
                 if (fast && slots > 6 && ((uint64_t)n_vars * T >= 65536u || cpt_max * 4u >= 65536u)) fast = false; // packed slots are 16+16 bit
                 fast_slots = slots;
                 if (T > 256 && !fast) continue;
+                // step-parallel form: worth it while the chain-per-lane form cannot fill the SIMDs
+                par = false;
+                if (fast && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && o.n_chains / 64u <= 4096u) {
+                    uint32_t nfree_max = 0;
+                    for (const auto &im : image) nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)im.free_vars.size());
+                    uint32_t b2 = ((uint32_t)n_vars * kParStateStride + 15u) & ~15u;
+                    par_hist_off = b2; b2 += ((uint32_t)H * 4u + 15u) & ~15u;
+                    par_tab_off = b2; b2 += cpt_max * 4u;
+                    par_rec_off = b2; b2 += nfree_max * kRecDwords * 4u;
+                    par_plan_off = b2; b2 += 4u * 2048u;
+                    par_scr_off = b2; b2 += 4u * 64u * 16u;
+                    par_lds = b2;
+                    const bool packed_ok = slots <= 6 || ((uint64_t)n_vars * kParStateStride < 65536u && cpt_max * 4u < 65536u);
+                    par = b2 <= kLdsBudget && packed_ok && (o.n_variants == 1 || cpv % 64u == 0);
+                }
                 return;
             }
         }
@@ -266,10 +283,33 @@ void gr_sampler::rebuild() {
         }
         d_variants.upload(h_variants, stream); // now with rec_base
         d_recs.upload(recs, stream);
+        if (par) { // same records for the step-parallel layout: 80-byte state rows, block-level histogram
+            std::vector<uint32_t> rp;
+            for (uint32_t g = 0; g < o.n_variants; ++g) {
+                const VariantImage &im = image[g];
+                for (uint32_t v : im.free_vars) {
+                    const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
+                    const uint32_t nn = (cp[0] >> 8) & 0xffu;
+                    uint32_t r[kRecDwords] = {0};
+                    r[0] = v * kParStateStride;
+                    r[1] = par_hist_off + cp[1] * 4u;
+                    r[2] = par_tab_off + cp[2] * 4u;
+                    r[3] = nn;
+                    const bool packed = fast_slots > 6;
+                    for (uint32_t i = 0; i < (packed ? 12u : 6u); ++i) {
+                        const uint32_t off = (i < nn ? cp[3 + 2 * i] : v) * kParStateStride, m4 = (i < nn ? cp[4 + 2 * i] : 0u) * 4u;
+                        if (packed) r[4 + i] = off | (m4 << 16);
+                        else { r[4 + 2 * i] = off; r[5 + 2 * i] = m4; }
+                    }
+                    rp.insert(rp.end(), r, r + kRecDwords);
+                }
+            }
+            d_recs_par.upload(rp, stream);
+        }
         const uint64_t waves = o.n_chains / 64u;
         uint64_t ps = (64ull << 20) / (waves * 4ull); // <= 64 MiB of plan per launch
-        ps = std::min<uint64_t>(ps, kMaxStepsPerLaunch) & ~3ull;
-        plan_steps = (uint32_t)std::max<uint64_t>(ps, 4);
+        ps = std::min<uint64_t>(ps, kMaxStepsPerLaunch) & ~15ull;
+        plan_steps = (uint32_t)std::max<uint64_t>(ps, 16);
         d_plan.alloc((size_t)waves * plan_steps + 16);
     }
     sync();
@@ -337,15 +377,19 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
         f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi;
         f.counting = p.counting; f.lds_hist_off = lds_hist_off; f.lds_tab_off = lds_tab_off; f.lds_plan_off = lds_plan_off;
+        f.recs_par = d_recs_par.p; f.par_hist_off = par_hist_off; f.par_tab_off = par_tab_off; f.par_rec_off = par_rec_off;
+        f.par_plan_off = par_plan_off; f.par_scr_off = par_scr_off;
+        const uint64_t gran = par ? 16 : 4; // steps per inner iteration of the fast kernels
         uint64_t left = updates;
-        const uint64_t head = std::min<uint64_t>(left, (4 - (step & 3)) & 3);
+        const uint64_t head = std::min<uint64_t>(left, (gran - (step % gran)) % gran);
         if (head) { generic_small(head); left -= head; }
-        while (left >= 4) {
-            const uint32_t n = (uint32_t)std::min<uint64_t>(left & ~3ull, plan_steps);
+        while (left >= gran) {
+            const uint32_t n = (uint32_t)std::min<uint64_t>(left - left % gran, plan_steps);
             f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
             f.n_steps = n;
             hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
-            hip_check(launch_sweep_bin(f, fast_slots, blocks, T, lds, stream), "k_sweep_bin launch");
+            if (par) hip_check(launch_sweep_par4(f, fast_slots, o.n_chains / 64u, par_lds, stream), "k_sweep_par4 launch");
+            else hip_check(launch_sweep_bin(f, fast_slots, blocks, T, lds, stream), "k_sweep_bin launch");
             step += n;
             left -= n;
             launches_last++;
@@ -882,7 +926,7 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         if (!s || !out || out->struct_size != sizeof(gr_sampler_info)) throw Error(GR_E_INVALID, "bad gr_sampler_info");
         if (s->dirty) { s->use(); s->configure(); }
         out->block_threads = s->T; out->n_blocks = s->blocks; out->lds_bytes = s->lds;
-        out->path = s->fast ? 2u : (s->cpt ? 1u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
+        out->path = s->fast ? (s->par ? 3u : 2u) : (s->cpt ? 1u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

@@ -44,21 +44,32 @@ __global__ void __launch_bounds__(256) k_scan_plan(const FastParams p) {
     const VariantDesc vd = p.variants[variant];
     const u32x4 sc = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)(gchain0 >> 6), DOM_SCAN, p.seed_lo, p.seed_hi);
     const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w};
-    uint32_t k[4], v[4], out[4];
+    uint32_t k[4], v[4], out[4], level[4], maxlv = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         k[j] = mul_hi_u32(su[j], vd.n_free);
         v[j] = p.free_vars[vd.free_base + k[j]];
-        // does step j read a variable that an earlier step of the quad writes?
+        // dependency level of step j inside its quad: 1 + the highest level of an earlier step that
+        // updates the same variable or one of its neighbours (blankets are symmetric, so this also
+        // covers "a later step overwrites what an earlier one still has to read").  Level 0 = commutes
+        // with everything before it.
         const uint32_t *cp = p.cprogs + vd.cprog_base + p.cprog_off[vd.cprogoff_base + v[j]];
         const uint32_t nn = (cp[0] >> 8) & 0xffu;
-        uint32_t conf = 0;
-        for (uint32_t i = 0; i < nn; ++i) {
-            const uint32_t nb = cp[3 + 2 * i];
-            for (int pj = 0; pj < j; ++pj) conf |= (nb == v[pj]) ? 1u : 0u;
+        uint32_t lv = 0, adj_any = 0;
+        for (int pj = 0; pj < j; ++pj) {
+            uint32_t dep = (v[pj] == v[j]) ? 1u : 0u, adj = 0;
+            for (uint32_t i = 0; i < nn; ++i) adj |= (cp[3 + 2 * i] == v[pj]) ? 1u : 0u;
+            adj_any |= adj;
+            if (dep | adj) lv = max(lv, level[pj] + 1u);
         }
-        out[j] = (vd.rec_base + k[j]) * (kRecDwords * 4u) | conf;
+        level[j] = lv;
+        maxlv = max(maxlv, lv);
+        // bit 0: reads a neighbour written earlier in the quad (k_sweep_bin recomputes it);
+        // bits 1-2: level (k_sweep_par4)
+        out[j] = (vd.rec_base + k[j]) * (kRecDwords * 4u) | adj_any | (lv << 1);
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] |= maxlv << 3; // bits 3-4: highest level in the quad, in every word
     reinterpret_cast<uint4 *>(p.plan + (size_t)wave * p.plan_pitch)[qi] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
@@ -70,7 +81,7 @@ struct Rec {
 // that a uniform address always becomes a scalar (s_load) access served by the scalar cache.
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
 __device__ __forceinline__ void load_rec(Rec &r, const uint32_t *recs, uint32_t plan_word) {
-    const_u32_ptr rp = (const_u32_ptr)(uintptr_t)(reinterpret_cast<const unsigned char *>(recs) + (plan_word & ~1u));
+    const_u32_ptr rp = (const_u32_ptr)(uintptr_t)(reinterpret_cast<const unsigned char *>(recs) + (plan_word & ~63u));
 #pragma unroll
     for (int i = 0; i < kRecDwords; ++i) r.w[i] = rp[i];
 }
@@ -250,6 +261,205 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
             const uint32_t c = h[i];
             if (c) atomicAdd(&gc[i], (unsigned long long)c);
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1, step-parallel form: 4 lanes per chain, one per step of a quad.
+//
+// With few chains (65 536 = one wavefront per SIMD in the chain-per-lane form) a lone wavefront
+// issues one instruction per 4 cycles and nothing hides its latencies.  Here a 256-lane block owns
+// 64 chains (one scan group); lane = (chain c, step slot j): the 4 steps of a quad are gathered,
+// drawn and committed side by side, so the same 65 536 chains run as 4 096 wavefronts (4 per SIMD).
+// Steps of a quad that do not commute carry a dependency LEVEL in the plan (k_scan_plan): pass 0
+// commits level 0, and only when the quad has higher levels are the conditionals re-gathered and
+// the next level committed.  Every (chain, step) uses the same Philox word and the same threshold
+// table as in the other kernels: bit-identical results.
+//   state     lds[var * 80 + chain]           (80-byte rows: 4 different rows per access land on different banks)
+//   records   staged in LDS, read per lane (4 distinct records per access, broadcast inside a step slot)
+//   lanes     lane = j * 16 + c: a 16-lane LDS lane group / DPP row is one step slot
+//   draws     lane (j, c) computes Philox for quad 4*SQ + j of chain c; an LDS scratch transposes
+//             the 4x4 words so that lane (j, c) ends up with word j of quads 4*SQ .. 4*SQ+3
+//   counts    DPP row reduction of the 16 draws of a step slot, then one lane adds (zeros, ones)
+constexpr uint32_t kParStride = 80;
+
+template <int SLOTS, bool PACKED>
+struct RecL { // a record as per-lane VGPR values
+    uint4 h;                                 // state row offset, hist offset, table offset, nn
+    uint4 s[PACKED ? (SLOTS + 3) / 4 : (SLOTS + 1) / 2];
+};
+
+template <int SLOTS, bool PACKED>
+__device__ __forceinline__ uint32_t comp4(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
+
+template <int SLOTS, bool PACKED>
+__device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const unsigned char *lds_c, const unsigned char *lds, const uint32_t u) {
+    uint32_t cfg4 = 0;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        uint32_t off, m4;
+        if constexpr (PACKED) {
+            const uint32_t w = comp4<SLOTS, PACKED>(r.s[i / 4], i % 4);
+            off = w & 0xffffu;
+            m4 = w >> 16;
+        } else {
+            off = comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2));
+            m4 = comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2) + 1);
+        }
+        cfg4 += __umul24(m4, (uint32_t)lds_c[off]);
+    }
+    const uint32_t T = *reinterpret_cast<const uint32_t *>(lds + r.h.z + cfg4);
+    return (u >= T) ? 1u : 0u;
+}
+
+template <int SLOTS, bool PACKED, bool COUNT>
+__global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // lane = step slot * 16 + chain: every 16-lane LDS lane group reads ONE record / plan word
+    // (broadcast, no bank conflict) and a DPP row reduction sums a step's draws
+    const uint32_t j = lane >> 4;                    // step slot inside the quad
+    const uint32_t cb = wave * 16u + (lane & 15u);   // chain inside the block
+    const uint32_t chain = blockIdx.x * 64u + cb;
+    const uint32_t variant = (blockIdx.x * 64u) / p.chains_per_variant;
+    const VariantDesc vd = p.variants[variant];
+    {   // stage tables + records, this block's 64 chains, zero the block histogram
+        const uint32_t n4 = (vd.cpt_len + 3u) >> 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + p.par_tab_off);
+        for (uint32_t i = tid; i < n4; i += 256) dst[i] = src[i];
+        const uint4 *rs = reinterpret_cast<const uint4 *>(p.recs_par + (size_t)vd.rec_base * kRecDwords);
+        uint4 *rd = reinterpret_cast<uint4 *>(lds + p.par_rec_off);
+        for (uint32_t i = tid; i < vd.n_free * (kRecDwords / 4u); i += 256) rd[i] = rs[i];
+        for (uint32_t v = j; v < p.n_vars; v += 4) lds[v * kParStride + cb] = p.state[(size_t)v * p.pitch + chain];
+        uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
+        for (uint32_t i = tid; i < p.H; i += 256) h[i] = 0;
+    }
+    __syncthreads();
+
+    const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
+    const uint64_t q0 = (((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2;
+    const uint32_t nq = p.n_steps >> 2; // multiple of 4
+    const unsigned char *lds_c = lds + cb;
+    const uint32_t rec_bias = p.par_rec_off - vd.rec_base * (kRecDwords * 4u);
+
+    // the block's scan plan (all 4 waves walk the same plan), staged per wave through an LDS ring
+    const uint4 *gplan = reinterpret_cast<const uint4 *>(p.plan + (size_t)blockIdx.x * p.plan_pitch);
+    uint4 *ring = reinterpret_cast<uint4 *>(lds + p.par_plan_off + wave * (2u * kPlanChunk * 16u));
+    const uint32_t *ring_w = reinterpret_cast<const uint32_t *>(ring) + j;
+    const uint32_t nchunks = (nq + kPlanChunk - 1) / kPlanChunk;
+    auto gload = [&](uint32_t chunk) -> uint4 {
+        const uint32_t i = chunk * kPlanChunk + lane;
+        return gplan[i < nq ? i : nq - 1];
+    };
+    ring[lane] = gload(0);
+    uint4 stage = gload(nchunks > 1 ? 1 : 0);
+    uint32_t *scr = reinterpret_cast<uint32_t *>(lds + p.par_scr_off + wave * (64u * 16u));
+    uint4 *scr_w = reinterpret_cast<uint4 *>(scr) + lane;  // my 4 words
+    const uint32_t *scr_r = scr + (lane & 15u) * 4u + j;   // + k * 64: word j of lane (k, my chain)
+    const bool tail = (lane & 15u) == 15u;                 // holds the row sums after the DPP reduction
+
+    // commit the step slots whose level equals `pass`: write the new values, count them.
+    // The 16 chains of a step slot are one DPP row: row_shr 1,2,4,8 leave the number of ones in lane 15.
+    auto commit = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine) {
+        if (mine) lds[r.h.x + cb] = (unsigned char)val;
+        if constexpr (COUNT) {
+            int s1 = (int)val;
+            s1 += __builtin_amdgcn_update_dpp(0, s1, 0x111, 0xf, 0xf, true);
+            s1 += __builtin_amdgcn_update_dpp(0, s1, 0x112, 0xf, 0xf, true);
+            s1 += __builtin_amdgcn_update_dpp(0, s1, 0x114, 0xf, 0xf, true);
+            s1 += __builtin_amdgcn_update_dpp(0, s1, 0x118, 0xf, 0xf, true);
+            if (mine && tail) {
+                uint32_t *hp = reinterpret_cast<uint32_t *>(__builtin_assume_aligned(lds + r.h.y, 4));
+                __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(hp + 1, (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+
+    for (uint32_t g0 = 0; g0 < nq; g0 += 4) {
+        if ((g0 & (kPlanChunk - 1u)) == kPlanChunk / 2u) {
+            const uint32_t nc = g0 / kPlanChunk + 1u;
+            if (nc < nchunks) {
+                ring[(nc & 1u) * kPlanChunk + lane] = stage;
+                if (nc + 1u < nchunks) stage = gload(nc + 1u);
+            }
+        }
+        // draws: my Philox call is quad g0 + j; transpose so that U[k] = my word of quad g0 + k
+        const uint64_t q = q0 + g0 + j;
+        const u32x4 W = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain,
+                                      DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
+        *scr_w = make_uint4(W.x, W.y, W.z, W.w);
+        uint32_t pw[4], U[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pw[k] = ring_w[((g0 + k) & (2u * kPlanChunk - 1u)) * 4u];
+            U[k] = scr_r[k * 64];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const unsigned char *ra = lds + rec_bias + (pw[k] & ~63u);
+            RecL<SLOTS, PACKED> r;
+            r.h = *reinterpret_cast<const uint4 *>(ra);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(r.s) / sizeof(uint4)); ++i) r.s[i] = *reinterpret_cast<const uint4 *>(ra + 16 + 16 * i);
+            const uint32_t lv = (pw[k] >> 1) & 3u;
+            const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
+            uint32_t val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+            commit(r, val, lv == 0);
+            if (maxlv >= 1) { // the quad has steps that do not commute: re-gather after the lower levels committed
+                val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+                commit(r, val, lv == 1);
+                if (maxlv >= 2) {
+                    val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+                    commit(r, val, lv == 2);
+                    if (maxlv >= 3) {
+                        val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+                        commit(r, val, lv == 3);
+                    }
+                }
+            }
+        }
+    }
+
+    for (uint32_t v = j; v < p.n_vars; v += 4) p.state[(size_t)v * p.pitch + chain] = lds[v * kParStride + cb];
+    if constexpr (COUNT) {
+        __syncthreads();
+        const uint32_t *h = reinterpret_cast<const uint32_t *>(lds + p.par_hist_off);
+        unsigned long long *gc = p.counts + (size_t)variant * p.H;
+        for (uint32_t i = tid; i < p.H; i += 256) {
+            const uint32_t c = h[i];
+            if (c) atomicAdd(&gc[i], (unsigned long long)c);
+        }
+    }
+}
+
+template <int SLOTS, bool PACKED>
+static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
+        return hipGetLastError();
+    };
+    return p.counting ? go(&k_sweep_par4<SLOTS, PACKED, true>) : go(&k_sweep_par4<SLOTS, PACKED, false>);
+}
+
+hipError_t launch_sweep_par4(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    switch (slots) {
+    case 0: case 1: return launch_par_t<1, false>(p, blocks, lds, s);
+    case 2: return launch_par_t<2, false>(p, blocks, lds, s);
+    case 3: return launch_par_t<3, false>(p, blocks, lds, s);
+    case 4: return launch_par_t<4, false>(p, blocks, lds, s);
+    case 5: return launch_par_t<5, false>(p, blocks, lds, s);
+    case 6: return launch_par_t<6, false>(p, blocks, lds, s);
+    case 7: return launch_par_t<7, true>(p, blocks, lds, s);
+    case 8: return launch_par_t<8, true>(p, blocks, lds, s);
+    case 9: return launch_par_t<9, true>(p, blocks, lds, s);
+    case 10: return launch_par_t<10, true>(p, blocks, lds, s);
+    case 11: return launch_par_t<11, true>(p, blocks, lds, s);
+    case 12: return launch_par_t<12, true>(p, blocks, lds, s);
+    default: return hipErrorInvalidValue;
     }
 }
 

@@ -101,6 +101,7 @@ int gr_error_suite(int32_t n_vars, const int32_t *card, const int32_t *fixed1, c
  * NewGibbsSimple / NewGibbsCollapsed (+ Collapse) for each of its chains. */
 #define GR_FLAG_DIRECT (1u << 0)      /* never memoise conditionals into tables (debug / cross-check) */
 #define GR_FLAG_SEQUENTIAL (1u << 1)  /* never co-issue commuting updates (debug / cross-check) */
+#define GR_FLAG_CHAIN_PER_LANE (1u << 2) /* never use the step-parallel (4 lanes per chain) kernel */
 
 typedef struct gr_sampler_opts {
     uint32_t struct_size;    /* = sizeof(gr_sampler_opts) */
@@ -181,7 +182,7 @@ typedef struct gr_sampler_info {
     uint32_t block_threads;
     uint32_t n_blocks;
     uint32_t lds_bytes;
-    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path) */
+    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path), 3 = same, step-parallel (4 lanes per chain) */
     uint32_t max_card;
     uint32_t tables_in_lds;
     uint32_t n_launches_last;

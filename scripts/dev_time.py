@@ -13,8 +13,10 @@ def timing(name, nch, sweeps, flags=0, bt=0, nvar=1):
     ups = nch * n * sweeps / (i['kernel_ms_last'] * 1e-3)
     print(f"time {name} chains={nch} flags={flags} bt={i['block_threads']} path={i['path']} lds={i['lds_bytes']} launches={i['n_launches_last']}: {i['kernel_ms_last']:.2f} ms for {sweeps} sweeps -> {ups:.3e} updates/s", flush=True)
 if __name__ == "__main__":
-    for bt in (0, 64, 128, 512, 1024):
-        timing("Grids_13.uai", 65536, 1000, 0, bt)
+    timing("Grids_13.uai", 65536, 1000, 0)
+    timing("Grids_13.uai", 65536, 1000, g.GR_FLAG_CHAIN_PER_LANE)
+    timing("Grids_13.uai", 131072, 500, 0)
+    timing("Grids_13.uai", 32768, 1000, 0)
     timing("Grids_13.uai", 65536, 1000, g.GR_FLAG_SEQUENTIAL)
     timing("Grids_13.uai", 1 << 20, 200, 0)
     timing("Grids_13.uai", 1 << 18, 400, 0)
