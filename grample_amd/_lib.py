@@ -19,7 +19,7 @@ class ModelDesc(C.Structure):
 class SamplerOpts(C.Structure):
     _fields_ = [("struct_size", u32), ("n_chains", u32), ("n_variants", u32), ("device", i32), ("seed", u64),
                 ("chain_offset", u64), ("variant_offset", u32), ("flags", u32), ("block_threads", u32),
-                ("reserved", u32)]
+                ("fast_form", u32)]
 
 
 class SamplerInfo(C.Structure):

@@ -202,10 +202,10 @@ class HIPChains:
     """n_chains sampler.Chain objects + their FullSampler on one MI355X."""
 
     def __init__(self, model, n_chains, n_variants=1, device=0, seed=42, chain_offset=0, variant_offset=0, flags=0,
-                 block_threads=0):
+                 block_threads=0, fast_form=0):
         self.L = _lib.lib()
         o = SamplerOpts(C.sizeof(SamplerOpts), n_chains, n_variants, device, seed, chain_offset, variant_offset, flags,
-                        block_threads, 0)
+                        block_threads, fast_form)
         self.ptr = self.L.gr_sampler_create(model.ptr, C.byref(o))
         if not self.ptr:
             raise _err()

@@ -39,7 +39,7 @@ hipError_t launch_collapse(const CollapseArgs &a, uint32_t blocks, hipStream_t s
 // fast binary / memoised path (sweep_bin.hip)
 hipError_t launch_scan_plan(const FastParams &p, hipStream_t s);
 hipError_t launch_sweep_bin(const FastParams &p, int slots, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s);
-hipError_t launch_sweep_par4(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s);
+hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t lds, hipStream_t s);
 constexpr uint32_t kParStateStride = 80; // must match kParStride in sweep_bin.hip
 
 } // namespace gr

@@ -101,6 +101,7 @@ struct gr_sampler {
     int fast_slots = 0;               // max neighbours of any selectable variable
     uint32_t plan_steps = 0;          // steps per fast launch (plan row length)
     DevBuf<uint32_t> d_recs, d_plan, d_recs_par;
+    bool par_packed = false;          // step-parallel records use one dword per neighbour
     bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
     uint32_t par_hist_off = 0, par_tab_off = 0, par_rec_off = 0, par_plan_off = 0, par_scr_off = 0, par_lds = 0;
     // device pools
@@ -194,8 +195,13 @@ void gr_sampler::configure() {
                 fast_slots = slots;
                 if (T > 256 && !fast) continue;
                 // step-parallel form: worth it while the chain-per-lane form cannot fill the SIMDs
+                // step-parallel form (4 lanes per chain): wins while the chain-per-lane form leaves SIMDs with
+                // a single wavefront (measured on Grids_13: 4.9e11 vs 4.1e11 updates/s at 65 536 chains,
+                // 5.0e11 vs 6.2e11 at 131 072)
                 par = false;
-                if (fast && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && o.n_chains / 64u <= 4096u) {
+                const uint32_t form = o.fast_form; // 0 auto, 1 chain per lane, 2 four lanes per chain
+                if (fast && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && form != 1 &&
+                    (form == 2 || o.n_chains / 64u <= 1536u)) {
                     uint32_t nfree_max = 0;
                     for (const auto &im : image) nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)im.free_vars.size());
                     uint32_t b2 = ((uint32_t)n_vars * kParStateStride + 15u) & ~15u;
@@ -205,8 +211,9 @@ void gr_sampler::configure() {
                     par_plan_off = b2; b2 += 4u * 2048u;
                     par_scr_off = b2; b2 += 4u * 64u * 16u;
                     par_lds = b2;
-                    const bool packed_ok = slots <= 6 || ((uint64_t)n_vars * kParStateStride < 65536u && cpt_max * 4u < 65536u);
-                    par = b2 <= kLdsBudget && packed_ok && (o.n_variants == 1 || cpv % 64u == 0);
+                    const bool fits16 = (uint64_t)n_vars * kParStateStride < 65536u && cpt_max * 4u < 65536u;
+                    par_packed = fits16;
+                    par = b2 <= kLdsBudget && (slots <= 6 || fits16) && (o.n_variants == 1 || cpv % 64u == 0);
                 }
                 return;
             }
@@ -295,7 +302,7 @@ void gr_sampler::rebuild() {
                     r[1] = par_hist_off + cp[1] * 4u;
                     r[2] = par_tab_off + cp[2] * 4u;
                     r[3] = nn;
-                    const bool packed = fast_slots > 6;
+                    const bool packed = par_packed;
                     for (uint32_t i = 0; i < (packed ? 12u : 6u); ++i) {
                         const uint32_t off = (i < nn ? cp[3 + 2 * i] : v) * kParStateStride, m4 = (i < nn ? cp[4 + 2 * i] : 0u) * 4u;
                         if (packed) r[4 + i] = off | (m4 << 16);
@@ -306,6 +313,7 @@ void gr_sampler::rebuild() {
             }
             d_recs_par.upload(rp, stream);
         }
+
         const uint64_t waves = o.n_chains / 64u;
         uint64_t ps = (64ull << 20) / (waves * 4ull); // <= 64 MiB of plan per launch
         ps = std::min<uint64_t>(ps, kMaxStepsPerLaunch) & ~15ull;
@@ -388,7 +396,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
             f.n_steps = n;
             hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
-            if (par) hip_check(launch_sweep_par4(f, fast_slots, o.n_chains / 64u, par_lds, stream), "k_sweep_par4 launch");
+            if (par) hip_check(launch_sweep_par4(f, fast_slots, par_packed, o.n_chains / 64u, par_lds, stream), "k_sweep_par4 launch");
             else hip_check(launch_sweep_bin(f, fast_slots, blocks, T, lds, stream), "k_sweep_bin launch");
             step += n;
             left -= n;

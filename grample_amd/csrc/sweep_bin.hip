@@ -445,7 +445,17 @@ static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t ld
     return p.counting ? go(&k_sweep_par4<SLOTS, PACKED, true>) : go(&k_sweep_par4<SLOTS, PACKED, false>);
 }
 
-hipError_t launch_sweep_par4(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s) {
+hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    if (packed) // one dword per neighbour: fewer LDS bytes per step, this form's bottleneck
+        switch (slots) {
+        case 0: case 1: return launch_par_t<1, true>(p, blocks, lds, s);
+        case 2: return launch_par_t<2, true>(p, blocks, lds, s);
+        case 3: return launch_par_t<3, true>(p, blocks, lds, s);
+        case 4: return launch_par_t<4, true>(p, blocks, lds, s);
+        case 5: return launch_par_t<5, true>(p, blocks, lds, s);
+        case 6: return launch_par_t<6, true>(p, blocks, lds, s);
+        default: break;
+        }
     switch (slots) {
     case 0: case 1: return launch_par_t<1, false>(p, blocks, lds, s);
     case 2: return launch_par_t<2, false>(p, blocks, lds, s);

@@ -113,7 +113,7 @@ typedef struct gr_sampler_opts {
     uint32_t variant_offset; /* global index of this device's variant 0 */
     uint32_t flags;          /* GR_FLAG_* */
     uint32_t block_threads;  /* 0 = auto; else 64/128/256 */
-    uint32_t reserved;
+    uint32_t fast_form;      /* tuning of the binary fast path: 0 = auto; 1 = chain per lane; 2 = 4 lanes per chain */
 } gr_sampler_opts;
 
 /* NewGibbsSimple for every chain (gibbs-simple.go:25-115): clones the model,
@@ -182,7 +182,7 @@ typedef struct gr_sampler_info {
     uint32_t block_threads;
     uint32_t n_blocks;
     uint32_t lds_bytes;
-    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path), 3 = same, step-parallel (4 lanes per chain) */
+    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path), 3 = same, 4 lanes per chain */
     uint32_t max_card;
     uint32_t tables_in_lds;
     uint32_t n_launches_last;

@@ -3,9 +3,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import grample_amd as g
 RES = os.path.join(ROOT, "tests", "golden", "res")
-def timing(name, nch, sweeps, flags=0, bt=0, nvar=1):
+def timing(name, nch, sweeps, flags=0, bt=0, nvar=1, form=0):
     m = g.Model.NewModelFromFile(os.path.join(RES, name))
-    s = g.HIPChains(m, nch, n_variants=nvar, flags=flags, block_threads=bt)
+    s = g.HIPChains(m, nch, n_variants=nvar, flags=flags, block_threads=bt, fast_form=form)
     n = m.n_vars
     s.BurnIn(n * 10)
     s.Advance(n * sweeps)
@@ -13,10 +13,9 @@ def timing(name, nch, sweeps, flags=0, bt=0, nvar=1):
     ups = nch * n * sweeps / (i['kernel_ms_last'] * 1e-3)
     print(f"time {name} chains={nch} flags={flags} bt={i['block_threads']} path={i['path']} lds={i['lds_bytes']} launches={i['n_launches_last']}: {i['kernel_ms_last']:.2f} ms for {sweeps} sweeps -> {ups:.3e} updates/s", flush=True)
 if __name__ == "__main__":
-    timing("Grids_13.uai", 65536, 1000, 0)
-    timing("Grids_13.uai", 65536, 1000, g.GR_FLAG_CHAIN_PER_LANE)
-    timing("Grids_13.uai", 131072, 500, 0)
-    timing("Grids_13.uai", 32768, 1000, 0)
+    for form in (2, 1):
+        for nch in (32768, 65536, 131072, 262144):
+            timing("Grids_13.uai", nch, 65536 * 500 // nch, 0, 0, 1, form)
     timing("Grids_13.uai", 65536, 1000, g.GR_FLAG_SEQUENTIAL)
     timing("Grids_13.uai", 1 << 20, 200, 0)
     timing("Grids_13.uai", 1 << 18, 400, 0)
