@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 MODEL = "Grids_13.uai"
 CHAINS_PER_GPU = 65536
-SWEEPS_PER_STEP = 100
+SWEEPS_PER_STEP = 1000
 BURNIN_SWEEPS = 200
 # SURVEY.md 8(d) / BASELINE.md: algorithmic bytes per single-variable update on Grids_13
 # (u8 state gathers 4 + f32 table reads 40 + state write 1 + counter RMW 8)
@@ -95,15 +95,11 @@ def main():
     upd_per_step = SWEEPS_PER_STEP * n_vars
     sampler.BurnIn(BURNIN_SWEEPS * n_vars)  # NewChain burn-in (chain.go:166-172), not timed
 
-    counts_t = torch.zeros(int(cards.sum()), dtype=torch.int64, device="cuda")
+    from grample_amd.dist import allreduce_counts
 
     def reduce_counts():
-        """the path's only exchange: all-reduce(sum) of the per-variable histograms"""
-        c = sampler.counts()[0].astype(np.int64)
-        counts_t.copy_(torch.from_numpy(c))
-        if dist is not None:
-            dist.all_reduce(counts_t, op=dist.ReduceOp.SUM)
-        return counts_t.cpu().numpy()
+        """the path's only exchange: all-reduce(sum) of the per-variable histograms (RCCL when world > 1)"""
+        return allreduce_counts(sampler.counts()[0], device="cuda")
 
     def barrier():
         if dist is not None:
@@ -160,13 +156,13 @@ def main():
                                    f"({upd_per_step} single-variable updates per chain) per step",
                        "chains_total": world * CHAINS_PER_GPU, "burnin_sweeps": BURNIN_SWEEPS,
                        "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-reduce of 200 counters at the end",
-                       "kernel": {"path": "memoised" if info["path"] else "direct", "block_threads": info["block_threads"],
-                                  "blocks": info["n_blocks"], "lds_bytes": info["lds_bytes"]}},
+                       "kernel": {"path": {0: "direct", 1: "memoised", 2: "memoised+plan, chain per lane",
+                                           3: "memoised+plan, 4 lanes per chain"}[info["path"]]}},
             "hellinger_vs_MAR": {"mean": es["MeanHellinger"], "max": es["MaxHellinger"], "mean_abs_err": es["MeanMeanAbsError"]},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "note": f"algorithmic {ALGO_BYTES_PER_UPDATE} B/update x {per_launch_updates:.0f} updates/launch / "
-                                 f"{per_launch_s * 1e3:.3f} ms mean k_sweep launch (HIP events on the sampler stream); "
+                                 f"{per_launch_s * 1e3:.3f} ms mean launch (k_scan_plan + sweep kernel, HIP events on the sampler stream); "
                                  "chain state + tables are LDS-resident, so real HBM traffic is far below the algorithmic bytes"},
         }
         if world == 1 and not args.no_cpu_baseline:
