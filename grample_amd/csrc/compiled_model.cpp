@@ -99,6 +99,34 @@ VariantImage CompileVariant(const Model &m, const CompileLimits &lim) {
     }
     while (im.views.size() % 4) im.views.push_back(0.f);
 
+    // ---- pairwise fixed-stride form of the same programs
+    im.pairwise = true;
+    for (const auto &f : m.Funcs)
+        if (f.Vars.size() > 2) im.pairwise = false;
+    im.pprog_off.assign(N, 0);
+    if (im.pairwise) {
+        for (int v = 0; v < N; ++v) {
+            while (im.pprog.size() % 4) im.pprog.push_back(0);
+            im.pprog_off[v] = (uint32_t)im.pprog.size();
+            const uint32_t *pg = im.prog.data() + im.prog_off[v];
+            const uint32_t nf = pg[0] >> 16;
+            im.pprog.push_back(pg[0]);
+            im.pprog.push_back(pg[1]);
+            im.pprog.push_back(0);
+            im.pprog.push_back(0);
+            const uint32_t *q = pg + 2;
+            for (uint32_t f = 0; f < nf; ++f) {
+                const uint32_t toff = q[0], no = q[1];
+                im.pprog.push_back(toff);
+                im.pprog.push_back(no ? q[2] : (uint32_t)v);
+                im.pprog.push_back(no ? q[3] : 0u);
+                im.pprog.push_back(0);
+                q += 2 + 2 * no;
+            }
+        }
+        while (im.pprog.size() % 4) im.pprog.push_back(0);
+    }
+
     // ---- memoised programs: blanket (minus evidence variables, whose value is a constant)
     im.cpt_ok = true;
     uint64_t words = 0;

@@ -34,6 +34,12 @@ struct VariantImage {
     std::vector<uint32_t> prog;     // direct programs, all variables
     std::vector<uint32_t> prog_off; // [n_vars] word offset of each variable's direct program
     std::vector<float> views;       // view-table pool (f32 log potentials)
+    // pairwise form of the direct program (only when every factor has arity <= 2): per variable
+    //   [0] Card | rowlen << 8 | n_factors << 16, [1] histogram offset, [2..3] pad, then per factor one
+    //   16-byte entry {view offset, other var (the variable itself for a unary factor), stride (0 for unary), 0}
+    // fixed stride => every factor's entry is an independent scalar load.
+    bool pairwise = false;
+    std::vector<uint32_t> pprog, pprog_off;
     std::vector<uint32_t> free_vars;// selectable variables: FixedVal < 0 and not Collapsed (sampler.go:146-156)
     bool cpt_ok = false;            // memoised path available
     std::vector<uint32_t> cprog;    // memoised programs

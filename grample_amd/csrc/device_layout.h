@@ -17,7 +17,7 @@ struct VariantDesc {
     uint32_t cpt_base;     // words, into cpt
     uint32_t cpt_len;      // words
     uint32_t rec_base;     // records (kRecDwords each), into recs: one per entry of this group's free list
-    uint32_t pad1;
+    uint32_t pprog_base;   // words, into pprogs (pairwise fixed-stride direct programs); pprog_off shares progoff_base
 };
 
 struct SweepParams {
@@ -29,6 +29,8 @@ struct SweepParams {
     const uint32_t *cprogs;
     const uint32_t *cprog_off;
     const uint32_t *cpt;
+    const uint32_t *pprogs;     // pairwise fixed-stride direct programs (null unless every group is pairwise)
+    const uint32_t *pprog_off;
     unsigned char *state;       // [n_vars][pitch] chain-minor: one coalesced 64-B line per wave per variable
     unsigned long long *counts; // [n_variants][H]
     uint32_t n_vars;

@@ -40,23 +40,24 @@ __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin
 // here: shift by max(w) instead (identical after normalisation; keeps f32 exp in
 // range), f32 exp, everything after it in f64 like the reference.  The draw is
 // "value = #{ i : u >= T_i }" with u a 32-bit uniform and T_i = round(cum_i/tot * 2^32).
-template <int MAXC>
-__device__ __forceinline__ void thresholds(const float (&w)[MAXC], const int C, uint32_t (&T)[MAXC > 1 ? MAXC - 1 : 1]) {
+// FULL = the variable uses all MAXC values: same arithmetic, none of the per-value `i < C` scalar guards.
+template <int MAXC, bool FULL>
+__device__ __forceinline__ void thresholds_impl(const float (&w)[MAXC], const int C, uint32_t (&T)[MAXC > 1 ? MAXC - 1 : 1]) {
     float m = w[0];
 #pragma unroll
     for (int i = 1; i < MAXC; ++i)
-        if (i < C) m = fmaxf(m, w[i]);
+        if (FULL || i < C) m = fmaxf(m, w[i]);
     double d[MAXC];
     double tot = 0.0;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i)
-        if (i < C) {
+        if (FULL || i < C) {
             d[i] = (double)__expf(w[i] - m);
             tot += d[i];
         }
 #pragma unroll
     for (int i = 0; i < MAXC; ++i)
-        if (i < C) {
+        if (FULL || i < C) {
             if (d[i] < 1e-6 * tot) { // every value must stay possible (gibbs-simple.go:246-258)
                 const double delta = tot * 1e-6;
                 tot += delta;
@@ -66,12 +67,12 @@ __device__ __forceinline__ void thresholds(const float (&w)[MAXC], const int C, 
     double tot2 = 0.0; // WeightedSample re-sums the weights (sampler.go:110-116)
 #pragma unroll
     for (int i = 0; i < MAXC; ++i)
-        if (i < C) tot2 += d[i];
+        if (FULL || i < C) tot2 += d[i];
     const double scale = 4294967296.0 / tot2;
     double cum = 0.0;
 #pragma unroll
     for (int i = 0; i < MAXC - 1; ++i)
-        if (i < C - 1) {
+        if (FULL || i < C - 1) {
             cum += d[i];
             const double t = fmin(rint(cum * scale), 4294967295.0);
             T[i] = (uint32_t)t;
@@ -79,11 +80,22 @@ __device__ __forceinline__ void thresholds(const float (&w)[MAXC], const int C, 
 }
 
 template <int MAXC>
+__device__ __forceinline__ void thresholds(const float (&w)[MAXC], const int C, uint32_t (&T)[MAXC > 1 ? MAXC - 1 : 1]) {
+    if (C == MAXC) thresholds_impl<MAXC, true>(w, C, T);
+    else thresholds_impl<MAXC, false>(w, C, T);
+}
+
+template <int MAXC>
 __device__ __forceinline__ uint32_t pick(const uint32_t (&T)[MAXC > 1 ? MAXC - 1 : 1], const int C, const uint32_t u) {
     uint32_t val = 0;
+    if (C == MAXC) {
 #pragma unroll
-    for (int i = 0; i < MAXC - 1; ++i)
-        if (i < C - 1) val += (u >= T[i]) ? 1u : 0u;
+        for (int i = 0; i < MAXC - 1; ++i) val += (u >= T[i]) ? 1u : 0u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAXC - 1; ++i)
+            if (i < C - 1) val += (u >= T[i]) ? 1u : 0u;
+    }
     return val;
 }
 
@@ -125,13 +137,68 @@ __device__ __forceinline__ void log_weights(const uint32_t *__restrict__ pg, con
     }
 }
 
+// Pairwise models (arity <= 2), fixed-stride program: every factor's entry is an independent
+// scalar load, and the table rows of up to GF factors are all requested before the first one is
+// consumed -- one table round trip per group instead of one per factor (the rows come from L2 when
+// the view tables do not fit LDS: ObjectDetection_13).  Accumulation stays in Model.Funcs order, so
+// the sums are bit-identical to log_weights().
+template <int MAXC, int GF, class Getter>
+__device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, const float *tab, Getter get, float (&w)[MAXC],
+                                               const uint32_t p0, const uint32_t p1, const uint32_t p2, bool &conflict) {
+    const uint32_t h = pg[0];
+    const uint32_t rowlen = (h >> 8) & 0xffu;
+    const uint32_t nf = h >> 16;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) w[i] = 0.f;
+    const uint4 *ent = reinterpret_cast<const uint4 *>(pg + 4);
+    constexpr int NV = MAXC <= 2 ? 1 : MAXC / 4;
+    const bool full = rowlen == (uint32_t)MAXC; // every row chunk is used: no per-chunk guards
+    for (uint32_t f0 = 0; f0 < nf; f0 += GF) {
+        const float *row[GF];
+#pragma unroll
+        for (int i = 0; i < GF; ++i)
+            if (f0 + i < nf) {
+                const uint4 e = ent[f0 + i];
+                conflict |= (e.y == p0) | (e.y == p1) | (e.y == p2);
+                row[i] = tab + (e.x + e.z * get(e.y));
+            }
+        float4 r[GF][NV];
+#pragma unroll
+        for (int i = 0; i < GF; ++i)
+            if (f0 + i < nf) {
+                if constexpr (MAXC <= 2) {
+                    const float2 t = *reinterpret_cast<const float2 *>(row[i]);
+                    r[i][0] = make_float4(t.x, t.y, 0.f, 0.f);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+                        if (full || (uint32_t)(4 * c) < rowlen) r[i][c] = *reinterpret_cast<const float4 *>(row[i] + 4 * c);
+                }
+            }
+#pragma unroll
+        for (int i = 0; i < GF; ++i)
+            if (f0 + i < nf) {
+                if constexpr (MAXC <= 2) {
+                    w[0] += r[i][0].x;
+                    w[1] += r[i][0].y;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < NV; ++c)
+                        if (full || (uint32_t)(4 * c) < rowlen) {
+                            w[4 * c] += r[i][c].x; w[4 * c + 1] += r[i][c].y; w[4 * c + 2] += r[i][c].z; w[4 * c + 3] += r[i][c].w;
+                        }
+                }
+            }
+    }
+}
+
 // ------------------------------------------------------------------- sweep
 // K1: n_steps single-variable updates on every chain of the block.
 //   CPT = false: conditionals computed from the view tables at every update;
 //   CPT = true : conditionals memoised per (variable, blanket configuration)
 //                by k_build_cpt -- one table word per binary update.
 //   TAB_LDS    : tables staged in LDS (else read from global through L1/L2).
-template <int MAXC, bool CPT, bool TAB_LDS>
+template <int MAXC, bool CPT, bool TAB_LDS, bool PW>
 __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t T = blockDim.x;
@@ -170,8 +237,8 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     const uint32_t wave_gid = uni((uint32_t)(gchain >> 6));
     const uint64_t step0 = ((uint64_t)p.step0_hi << 32) | p.step0_lo;
     const uint64_t step1 = step0 + p.n_steps;
-    const uint32_t *progs = (CPT ? p.cprogs + vd.cprog_base : p.progs + vd.prog_base);
-    const uint32_t *poff = (CPT ? p.cprog_off + vd.cprogoff_base : p.prog_off + vd.progoff_base);
+    const uint32_t *progs = CPT ? p.cprogs + vd.cprog_base : (PW ? p.pprogs + vd.pprog_base : p.progs + vd.prog_base);
+    const uint32_t *poff = CPT ? p.cprog_off + vd.cprogoff_base : (PW ? p.pprog_off + vd.progoff_base : p.prog_off + vd.progoff_base);
     const uint32_t *freev = p.free_vars + vd.free_base;
     const bool seq = p.sequential != 0;
     const bool counting = p.counting != 0;
@@ -198,7 +265,8 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
             return val;
         } else {
             float w[MAXC];
-            log_weights<MAXC>(pg, tab_f, get, w, p0, p1, p2, conflict);
+            if constexpr (PW) log_weights_pw<MAXC, (MAXC <= 16 ? 8 : (MAXC <= 32 ? 4 : 2))>(pg, tab_f, get, w, p0, p1, p2, conflict);
+            else log_weights<MAXC>(pg, tab_f, get, w, p0, p1, p2, conflict);
             uint32_t Th[MAXC > 1 ? MAXC - 1 : 1];
             thresholds<MAXC>(w, C, Th);
             return pick<MAXC>(Th, C, u);
@@ -416,23 +484,25 @@ __global__ void __launch_bounds__(256) k_collapse(const CollapseArgs a) {
         else { constexpr int MC = 64; __VA_ARGS__; }               \
     } while (0)
 
-template <int MC, bool CPT, bool TL>
+template <int MC, bool CPT, bool TL, bool PW>
 static hipError_t launch_sweep_t(const SweepParams &p, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<MC, CPT, TL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<MC, CPT, TL, PW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sweep<MC, CPT, TL>), dim3(blocks), dim3(threads), lds, s, p);
+    hipLaunchKernelGGL((k_sweep<MC, CPT, TL, PW>), dim3(blocks), dim3(threads), lds, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, uint32_t blocks, uint32_t threads,
+hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, uint32_t blocks, uint32_t threads,
                         uint32_t lds_bytes, hipStream_t s) {
     hipError_t e = hipSuccess;
     GR_DISPATCH_MAXC(max_card, {
-        if (cpt) e = tab_lds ? launch_sweep_t<MC, true, true>(p, blocks, threads, lds_bytes, s)
-                             : launch_sweep_t<MC, true, false>(p, blocks, threads, lds_bytes, s);
-        else e = tab_lds ? launch_sweep_t<MC, false, true>(p, blocks, threads, lds_bytes, s)
-                         : launch_sweep_t<MC, false, false>(p, blocks, threads, lds_bytes, s);
+        if (cpt) e = tab_lds ? launch_sweep_t<MC, true, true, false>(p, blocks, threads, lds_bytes, s)
+                             : launch_sweep_t<MC, true, false, false>(p, blocks, threads, lds_bytes, s);
+        else if (pairwise) e = tab_lds ? launch_sweep_t<MC, false, true, true>(p, blocks, threads, lds_bytes, s)
+                                       : launch_sweep_t<MC, false, false, true>(p, blocks, threads, lds_bytes, s);
+        else e = tab_lds ? launch_sweep_t<MC, false, true, false>(p, blocks, threads, lds_bytes, s)
+                         : launch_sweep_t<MC, false, false, false>(p, blocks, threads, lds_bytes, s);
     });
     return e;
 }

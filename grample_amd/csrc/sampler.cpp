@@ -106,7 +106,8 @@ struct gr_sampler {
     uint32_t par_hist_off = 0, par_tab_off = 0, par_rec_off = 0, par_plan_off = 0, par_scr_off = 0, par_lds = 0;
     // device pools
     DevBuf<VariantDesc> d_variants;
-    DevBuf<uint32_t> d_progs, d_prog_off, d_free, d_cprogs, d_cprog_off, d_cpt;
+    DevBuf<uint32_t> d_progs, d_prog_off, d_free, d_cprogs, d_cprog_off, d_cpt, d_pprogs, d_pprog_off;
+    bool pairwise = false;            // every group's model has arity <= 2: fixed-stride direct programs
     DevBuf<float> d_views;
     DevBuf<int32_t> d_card, d_fixed;
     DevBuf<unsigned char> d_state;
@@ -227,7 +228,9 @@ void gr_sampler::configure() {
 void gr_sampler::rebuild() {
     use();
     configure();
-    std::vector<uint32_t> progs, prog_off, freev, cprogs, cprog_off;
+    std::vector<uint32_t> progs, prog_off, freev, cprogs, cprog_off, pprogs, pprog_off;
+    pairwise = true;
+    for (const auto &im : image) pairwise = pairwise && im.pairwise;
     std::vector<float> views;
     h_variants.assign(o.n_variants, VariantDesc{});
     uint32_t cpt_total = 0;
@@ -244,6 +247,9 @@ void gr_sampler::rebuild() {
         vd.cprogoff_base = (uint32_t)cprog_off.size();
         vd.cpt_base = cpt_total;
         vd.cpt_len = cpt ? im.cpt_words : 0u;
+        vd.pprog_base = (uint32_t)pprogs.size();
+        pprogs.insert(pprogs.end(), im.pprog.begin(), im.pprog.end());
+        pprog_off.insert(pprog_off.end(), im.pprog_off.begin(), im.pprog_off.end());
         progs.insert(progs.end(), im.prog.begin(), im.prog.end());
         prog_off.insert(prog_off.end(), im.prog_off.begin(), im.prog_off.end());
         views.insert(views.end(), im.views.begin(), im.views.end());
@@ -259,6 +265,9 @@ void gr_sampler::rebuild() {
     d_free.upload(freev, stream);
     d_cprogs.upload(cprogs, stream);
     d_cprog_off.upload(cprog_off, stream);
+    pprogs.resize(pprogs.size() + 4, 0);
+    d_pprogs.upload(pprogs, stream);
+    d_pprog_off.upload(pprog_off, stream);
     d_cpt.alloc(cpt_total + 4);
     hip_check(hipMemsetAsync(d_cpt.p, 0, (cpt_total + 4) * sizeof(uint32_t), stream), "hipMemset");
     if (cpt)
@@ -343,6 +352,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     p.variants = d_variants.p;
     p.progs = d_progs.p; p.prog_off = d_prog_off.p; p.views = d_views.p; p.free_vars = d_free.p;
     p.cprogs = d_cprogs.p; p.cprog_off = d_cprog_off.p; p.cpt = d_cpt.p;
+    p.pprogs = d_pprogs.p; p.pprog_off = d_pprog_off.p;
     p.state = d_state.p; p.counts = d_counts.p;
     p.n_vars = (uint32_t)n_vars; p.H = (uint32_t)H; p.n_chains = o.n_chains; p.pitch = pitch;
     p.chains_per_variant = cpv;
@@ -358,7 +368,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
             p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
             p.n_steps = n;
-            hip_check(launch_sweep(p, max_card, cpt, tab_lds, blocks, T, lds, stream), "k_sweep launch");
+            hip_check(launch_sweep(p, max_card, cpt, tab_lds, pairwise, blocks, T, lds, stream), "k_sweep launch");
             step += n;
             left -= n;
             launches_last++;

@@ -23,3 +23,8 @@ if __name__ == "__main__":
     timing("Segmentation_11.uai", 32768, 200)
     timing("Segmentation_11.uai", 32768, 200, g.GR_FLAG_SEQUENTIAL)
     timing("ObjectDetection_13.uai", 32768, 100)
+    timing("ObjectDetection_13.uai", 65536, 100)
+    timing("ObjectDetection_13.uai", 262144, 50)
+    timing("Grids_13.uai", 65536, 200, g.GR_FLAG_DIRECT)
+    timing("CSP_12.uai", 32768, 100)
+    timing("Pedigree_11.uai", 32768, 50)

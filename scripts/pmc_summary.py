@@ -6,7 +6,7 @@ for d in sys.argv[2:]:
     rows = list(csv.DictReader(open(sorted(fs)[-1])))
     agg = collections.defaultdict(list)
     for r in rows:
-        if "k_sweep_bin" in r["Kernel_Name"] or "k_sweep_par4" in r["Kernel_Name"]:
+        if "k_sweep" in r["Kernel_Name"]:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
     for k, v in sorted(agg.items()):
         print(f"{d} {k:28s} last={v[-1]:.4g} per_quad={v[-1]/quads:.2f}")
