@@ -12,7 +12,13 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisi
 LIB := grample_amd/libgrample_hip.so
 OBJS := $(OBJDIR)/kernels.o $(OBJDIR)/sweep_bin.o $(OBJDIR)/sampler.o $(OBJDIR)/host_model.o $(OBJDIR)/compiled_model.o
 
-all: $(LIB) oracle
+TOOL := tools/grample_hip_sample
+
+all: $(LIB) oracle $(TOOL)
+
+# C++ host driver above the C ABI (links nothing but the library)
+$(TOOL): tools/grample_hip_sample.cpp include/grample_hip.h $(LIB)
+	g++ -O2 -std=c++17 -Wall -o $@ $< -Lgrample_amd -lgrample_hip -Wl,-rpath,'$$ORIGIN/../grample_amd' -Wl,-rpath,/opt/rocm/lib
 
 $(OBJDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h
 	@mkdir -p $(OBJDIR)
@@ -33,7 +39,7 @@ oracle:
 	$(MAKE) -s -C oracle liboracle.so
 
 clean:
-	rm -rf build $(LIB)
+	rm -rf build $(LIB) $(TOOL)
 	$(MAKE) -s -C oracle clean
 
 .PHONY: all oracle clean

@@ -79,12 +79,20 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Gibbs path has no CPU fallback")
+    # BENCH_REHEARSE_ONE_GPU=1: every rank uses GPU 0 and the collective runs over gloo -- lets the
+    # N > 1 code path (sharding, offsets, all-reduce, max-over-ranks timing) be rehearsed on a 1-GPU box.
+    rehearse = os.environ.get("BENCH_REHEARSE_ONE_GPU") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # "nccl" is RCCL on ROCm
 
     res_dir = os.path.join(ROOT, "tests", "golden", "res")
     model = g.Model.NewModelFromFile(os.path.join(res_dir, MODEL))
@@ -99,7 +107,7 @@ def main():
 
     def reduce_counts():
         """the path's only exchange: all-reduce(sum) of the per-variable histograms (RCCL when world > 1)"""
-        return allreduce_counts(sampler.counts()[0], device="cuda")
+        return allreduce_counts(sampler.counts()[0], device="cpu" if rehearse else "cuda")
 
     def barrier():
         if dist is not None:
@@ -121,10 +129,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dev = "cpu" if rehearse else "cuda"
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        k = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
+        k = torch.tensor([kernel_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(k, op=dist.ReduceOp.MAX)
         kernel_ms = float(k.item())
 

@@ -325,3 +325,42 @@ def test_state_roundtrip_and_errors(res_dir):
         g.HIPChains(m, 100, n_variants=3)
     with pytest.raises(g.GrError):
         g.HIPChains(m, 64, chain_offset=5)
+
+
+def test_cpp_host_driver(res_dir):
+    """tools/grample_hip_sample (C++ host above the C ABI, cmd/root.go's sample flow) runs Grids_11 and
+    reports the same Hellinger as the Python view of the same run."""
+    import subprocess
+    root = os.path.dirname(res_dir.rstrip("/").rsplit("/tests/", 1)[0] + "/x")
+    exe = os.path.join(root, "tools", "grample_hip_sample")
+    if not os.path.exists(exe):
+        pytest.skip("tools/grample_hip_sample not built")
+    out = subprocess.run([exe, "-m", os.path.join(res_dir, "Grids_11.uai"), "-o", "-c", "4096", "-b", "2000", "-i", "8000",
+                          "-r", "2", "-e", "42"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "DONE" in out.stdout
+    final = [ln for ln in out.stdout.splitlines() if ln.startswith("FINAL")][0]
+    mh = float(final.split("MeanHellinger=")[1].split()[0])
+    s = g.HIPChains.NewGibbsSimple(g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai")), 4096, seed=42)
+    s.BurnIn(2000); s.Advance(4000); s.Advance(4000)
+    pm = uai_py.load(res_dir, "Grids_11.uai")
+    es = g.NewErrorSuite(pm.card, uai_py.load_mar(res_dir, "Grids_11.uai"), g.MergeChains([s])[0])
+    assert mh == pytest.approx(es["MeanHellinger"], abs=1e-7)
+
+
+def test_bench_two_ranks_rehearsal():
+    """bench.py's N > 1 path (sharding by chain_offset, all-reduce, max-over-ranks timing), rehearsed with two
+    ranks on GPU 0 over gloo: the JSON line must report both ranks' chains."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_REHEARSE_ONE_GPU="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["chains_total"] == 2 * 65536 and d["value"] > 1e9
+    assert d["scaling"] == "weak" and "cpu_baseline" not in d
