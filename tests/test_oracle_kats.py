@@ -477,3 +477,22 @@ def test_collapse_errors(oracle, res_dir):
     assert L.orc_collapsed_collapse(c, 0) < 0  # "New function would have 0 variables"
     assert "0 variables" in oracle.err()
     L.orc_collapsed_free(c); L.orc_gen_free(g)
+
+
+# ------------------------------------------------------------ derived goldens
+def test_oracle_reproduces_committed_vectors(oracle):
+    """tests/golden/oracle_vectors.json (made by tests/golden/make_golden.py): the oracle is pinned
+    against silent change, and against the numbers SURVEY.md 8(c) obtained independently from
+    std::mt19937_64: first Float64 draws of seed 42 and the 255/769 split of 1024 one.uai draws."""
+    import importlib.util
+    import json
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = json.load(open(os.path.join(here, "golden", "oracle_vectors.json")))
+    got = json.loads(json.dumps(mg.build()))
+    assert got == want
+    assert [float(x) for x in want["mt_seed42_float64"]] == [0.55853149089588316, 0.73629461442040611, 0.39337113195856088]
+    assert want["one_uai_seed42_1024_draws_no_init"] == [255, 769]
