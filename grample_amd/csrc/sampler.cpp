@@ -152,7 +152,7 @@ void gr_sampler::configure() {
         if (tl) b += (use_cpt ? cpt_max : views_max) * 4u;
         b = (b + 15u) & ~15u;
         plan_off = b;
-        if (use_cpt && tl) b += (t / 64u) * 2048u; // fast path: per-wave scan-plan ring
+        if (use_cpt && tl) b += (t / 64u) * 1024u; // fast path: per-wave scan-plan ring (2 x 32 quads x 16 B)
         return b;
     };
     // fast path (sweep_bin.hip): every selectable variable binary, memoised tables, whole wavefronts
@@ -209,7 +209,7 @@ void gr_sampler::configure() {
                     par_hist_off = b2; b2 += ((uint32_t)H * 4u + 15u) & ~15u;
                     par_tab_off = b2; b2 += cpt_max * 4u;
                     par_rec_off = b2; b2 += nfree_max * kRecDwords * 4u;
-                    par_plan_off = b2; b2 += 4u * 2048u;
+                    par_plan_off = b2; b2 += 4u * 1024u;
                     par_scr_off = b2; b2 += 4u * 64u * 16u;
                     par_lds = b2;
                     const bool fits16 = (uint64_t)n_vars * kParStateStride < 65536u && cpt_max * 4u < 65536u;

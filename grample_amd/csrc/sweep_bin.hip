@@ -133,7 +133,7 @@ __device__ __forceinline__ uint32_t sample_rec(const Rec &r, const unsigned char
     return (u >= table_word<SLOTS, PACKED>(r, x, lds)) ? 1u : 0u;
 }
 
-constexpr uint32_t kPlanChunk = 64; // quads per staged plan chunk; the LDS ring holds two chunks per wave
+constexpr uint32_t kPlanChunk = 32; // quads per staged plan chunk (lanes 0..31 carry one quad each); the LDS ring holds two chunks per wave
 
 template <int SLOTS, bool PACKED, bool COUNT>
 __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
@@ -175,10 +175,10 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
     uint4 *ring = reinterpret_cast<uint4 *>(lds + p.lds_plan_off + wave * (2u * kPlanChunk * 16u));
     const uint32_t nchunks = (nq + kPlanChunk - 1) / kPlanChunk;
     auto gload = [&](uint32_t chunk) -> uint4 {
-        const uint32_t i = chunk * kPlanChunk + lane;
+        const uint32_t i = chunk * kPlanChunk + (lane & (kPlanChunk - 1u));
         return gplan[i < nq ? i : nq - 1];
     };
-    ring[lane] = gload(0);
+    if (lane < kPlanChunk) ring[lane] = gload(0);
     uint4 stage = gload(nchunks > 1 ? 1 : 0);
     auto ring_read = [&](uint32_t g) -> uint4 { return ring[(g < nq ? g : nq - 1) & (2u * kPlanChunk - 1u)]; };
 
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
             // mid-chunk: park the prefetched next chunk in the other half of the ring, fetch the one after it
             const uint32_t nc = qi / kPlanChunk + 1u;
             if (nc < nchunks) {
-                ring[(nc & 1u) * kPlanChunk + lane] = stage;
+                if (lane < kPlanChunk) ring[(nc & 1u) * kPlanChunk + lane] = stage;
                 if (nc + 1u < nchunks) stage = gload(nc + 1u);
             }
         }
@@ -349,10 +349,10 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     const uint32_t *ring_w = reinterpret_cast<const uint32_t *>(ring) + j;
     const uint32_t nchunks = (nq + kPlanChunk - 1) / kPlanChunk;
     auto gload = [&](uint32_t chunk) -> uint4 {
-        const uint32_t i = chunk * kPlanChunk + lane;
+        const uint32_t i = chunk * kPlanChunk + (lane & (kPlanChunk - 1u));
         return gplan[i < nq ? i : nq - 1];
     };
-    ring[lane] = gload(0);
+    if (lane < kPlanChunk) ring[lane] = gload(0);
     uint4 stage = gload(nchunks > 1 ? 1 : 0);
     uint32_t *scr = reinterpret_cast<uint32_t *>(lds + p.par_scr_off + wave * (64u * 16u));
     uint4 *scr_w = reinterpret_cast<uint4 *>(scr) + lane;  // my 4 words
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         if ((g0 & (kPlanChunk - 1u)) == kPlanChunk / 2u) {
             const uint32_t nc = g0 / kPlanChunk + 1u;
             if (nc < nchunks) {
-                ring[(nc & 1u) * kPlanChunk + lane] = stage;
+                if (lane < kPlanChunk) ring[(nc & 1u) * kPlanChunk + lane] = stage;
                 if (nc + 1u < nchunks) stage = gload(nc + 1u);
             }
         }
