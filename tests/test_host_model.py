@@ -209,3 +209,21 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
                 txt = open(os.path.join(dp, fn)).read()
                 assert "oracle" not in txt.lower().replace("the oracle's", ""), f"{fn} mentions the oracle"
+
+
+def test_host_code_under_sanitizers(res_dir, tmp_path):
+    """The product's host code (UAI reader, evidence, solutions, device-image compiler) under
+    AddressSanitizer + UBSan on every fixture and on malformed inputs (GPU sanitizers are not
+    available on this pool; the device side is covered by the bitwise replay tests instead)."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_asan")
+    src = [os.path.join(root, "tests", "host_asan_main.cpp"), os.path.join(root, "grample_amd", "csrc", "host_model.cpp"),
+           os.path.join(root, "grample_amd", "csrc", "compiled_model.cpp")]
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-o", exe] + src, check=True)
+    files = sorted(glob.glob(os.path.join(res_dir, "*.uai")))
+    out = subprocess.run([exe] + files, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "ERROR" not in out.stdout and out.stdout.count("image_words") == 2 * len(files)
