@@ -68,6 +68,7 @@ struct FastParams {
     unsigned char *state;
     unsigned long long *counts;
     uint32_t plan_pitch;        // words per wavefront row (multiple of 4)
+    uint32_t rec_stride;        // bytes per record: 64, or 128 when a variable has 13..16 neighbours (4-lane form only)
     uint32_t n_vars, H, n_chains, pitch, chains_per_variant;
     uint32_t chain_offset_lo, chain_offset_hi;
     uint32_t seed_lo, seed_hi;

@@ -102,6 +102,7 @@ struct gr_sampler {
     uint32_t plan_steps = 0;          // steps per fast launch (plan row length)
     DevBuf<uint32_t> d_recs, d_plan, d_recs_par;
     bool par_packed = false;          // step-parallel records use one dword per neighbour
+    uint32_t rec_stride = 64;         // bytes per record (128 when a variable has 13..16 neighbours)
     bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
     uint32_t par_hist_off = 0, par_tab_off = 0, par_rec_off = 0, par_plan_off = 0, par_scr_off = 0, par_lds = 0;
     // device pools
@@ -158,14 +159,18 @@ void gr_sampler::configure() {
     // fast path (sweep_bin.hip): every selectable variable binary, memoised tables, whole wavefronts
     bool fast_ok = all_cpt && !(o.flags & GR_FLAG_SEQUENTIAL) && (o.n_chains % 64u) == 0 && n_vars < 65536 && H < 16384;
     int slots = 0;
+    uint32_t max_mult = 1; // largest mixed-radix multiplier of any neighbour (packed records keep 4*mult in 16 bits)
     if (fast_ok)
         for (uint32_t g = 0; g < o.n_variants && fast_ok; ++g)
             for (uint32_t v : image[g].free_vars) {
                 const uint32_t *cp = image[g].cprog.data() + image[g].cprog_off[v];
                 if ((cp[0] & 0xffu) != 2u) { fast_ok = false; break; }
-                slots = std::max<int>(slots, (int)((cp[0] >> 8) & 0xffu));
+                const uint32_t nn = (cp[0] >> 8) & 0xffu;
+                slots = std::max<int>(slots, (int)nn);
+                for (uint32_t i = 0; i < nn; ++i) max_mult = std::max(max_mult, cp[4 + 2 * i]);
             }
-    if (slots > 12) fast_ok = false;
+    if (slots > 16) fast_ok = false;
+    const bool cpl_slots_ok = slots <= 12; // the chain-per-lane form keeps 4 records in SGPRs: 12 neighbours at most
     std::vector<uint32_t> cands;
     if (o.block_threads) {
         const uint32_t bt = o.block_threads;
@@ -191,8 +196,10 @@ void gr_sampler::configure() {
                 if (b > kLdsBudget) continue;
                 T = t; lds = b; lds_hist_off = ho; lds_tab_off = to; lds_plan_off = plan_off; cpt = use_cpt; tab_lds = tl;
                 blocks = (o.n_chains + T - 1) / T;
-                fast = fast_ok && use_cpt && tl && (o.n_chains % T) == 0;
-                if (fast && slots > 6 && ((uint64_t)n_vars * T >= 65536u || cpt_max * 4u >= 65536u)) fast = false; // packed slots are 16+16 bit
+                fast = fast_ok && cpl_slots_ok && use_cpt && tl && (o.n_chains % T) == 0;
+                if (fast && slots > 6 && ((uint64_t)n_vars * T >= 65536u || max_mult * 4u >= 65536u)) fast = false; // packed slots are 16+16 bit
+                const bool cpl_fast = fast;
+                rec_stride = slots > 12 ? 128u : 64u;
                 fast_slots = slots;
                 if (T > 256 && !fast) continue;
                 // step-parallel form: worth it while the chain-per-lane form cannot fill the SIMDs
@@ -201,20 +208,21 @@ void gr_sampler::configure() {
                 // 5.0e11 vs 6.2e11 at 131 072)
                 par = false;
                 const uint32_t form = o.fast_form; // 0 auto, 1 chain per lane, 2 four lanes per chain
-                if (fast && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && form != 1 &&
-                    (form == 2 || o.n_chains / 64u <= 1536u)) {
+                if (fast_ok && use_cpt && tl && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && form != 1 &&
+                    (form == 2 || o.n_chains / 64u <= 1536u || !cpl_fast)) {
                     uint32_t nfree_max = 0;
                     for (const auto &im : image) nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)im.free_vars.size());
                     uint32_t b2 = ((uint32_t)n_vars * kParStateStride + 15u) & ~15u;
                     par_hist_off = b2; b2 += ((uint32_t)H * 4u + 15u) & ~15u;
                     par_tab_off = b2; b2 += cpt_max * 4u;
-                    par_rec_off = b2; b2 += nfree_max * kRecDwords * 4u;
+                    par_rec_off = b2; b2 += nfree_max * rec_stride;
                     par_plan_off = b2; b2 += 4u * 1024u;
                     par_scr_off = b2; b2 += 4u * 64u * 16u;
                     par_lds = b2;
-                    const bool fits16 = (uint64_t)n_vars * kParStateStride < 65536u && cpt_max * 4u < 65536u;
+                    const bool fits16 = (uint64_t)n_vars * kParStateStride < 65536u && max_mult * 4u < 65536u;
                     par_packed = fits16;
-                    par = b2 <= kLdsBudget && (slots <= 6 || fits16) && (o.n_variants == 1 || cpv % 64u == 0);
+                    par = b2 <= kLdsBudget && (slots <= 6 || fits16) && (o.n_variants == 1 || cpv % 64u == 0) && (o.n_chains % 64u) == 0;
+                    if (par) fast = true;
                 }
                 return;
             }
@@ -277,9 +285,12 @@ void gr_sampler::rebuild() {
                       "k_build_cpt");
     if (fast) {
         std::vector<uint32_t> recs;
+        uint32_t rec_count = 0;
         for (uint32_t g = 0; g < o.n_variants; ++g) {
             const VariantImage &im = image[g];
-            h_variants[g].rec_base = (uint32_t)(recs.size() / kRecDwords);
+            h_variants[g].rec_base = rec_count;
+            rec_count += (uint32_t)im.free_vars.size();
+            if (fast_slots > 12) continue; // chain-per-lane records hold 12 neighbours; such models run the 4-lane form only
             for (uint32_t v : im.free_vars) {
                 const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
                 const uint32_t nn = (cp[0] >> 8) & 0xffu;
@@ -306,18 +317,18 @@ void gr_sampler::rebuild() {
                 for (uint32_t v : im.free_vars) {
                     const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
                     const uint32_t nn = (cp[0] >> 8) & 0xffu;
-                    uint32_t r[kRecDwords] = {0};
+                    uint32_t r[32] = {0};
                     r[0] = v * kParStateStride;
                     r[1] = par_hist_off + cp[1] * 4u;
                     r[2] = par_tab_off + cp[2] * 4u;
                     r[3] = nn;
                     const bool packed = par_packed;
-                    for (uint32_t i = 0; i < (packed ? 12u : 6u); ++i) {
+                    for (uint32_t i = 0; i < (packed ? (rec_stride == 128u ? 16u : 12u) : 6u); ++i) {
                         const uint32_t off = (i < nn ? cp[3 + 2 * i] : v) * kParStateStride, m4 = (i < nn ? cp[4 + 2 * i] : 0u) * 4u;
                         if (packed) r[4 + i] = off | (m4 << 16);
                         else { r[4 + 2 * i] = off; r[5 + 2 * i] = m4; }
                     }
-                    rp.insert(rp.end(), r, r + kRecDwords);
+                    rp.insert(rp.end(), r, r + rec_stride / 4u);
                 }
             }
             d_recs_par.upload(rp, stream);
@@ -391,6 +402,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p;
         f.cpt = d_cpt.p; f.recs = d_recs.p; f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p;
         f.plan_pitch = plan_steps;
+        f.rec_stride = rec_stride;
         f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = o.n_chains; f.pitch = pitch; f.chains_per_variant = cpv;
         f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
         f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi;

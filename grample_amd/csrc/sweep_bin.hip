@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(256) k_scan_plan(const FastParams p) {
         maxlv = max(maxlv, lv);
         // bit 0: reads a neighbour written earlier in the quad (k_sweep_bin recomputes it);
         // bits 1-2: level (k_sweep_par4)
-        out[j] = (vd.rec_base + k[j]) * (kRecDwords * 4u) | adj_any | (lv << 1);
+        out[j] = (vd.rec_base + k[j]) * p.rec_stride | adj_any | (lv << 1);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) out[j] |= maxlv << 3; // bits 3-4: highest level in the quad, in every word
@@ -328,9 +328,9 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
         uint4 *dst = reinterpret_cast<uint4 *>(lds + p.par_tab_off);
         for (uint32_t i = tid; i < n4; i += 256) dst[i] = src[i];
-        const uint4 *rs = reinterpret_cast<const uint4 *>(p.recs_par + (size_t)vd.rec_base * kRecDwords);
+        const uint4 *rs = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.recs_par) + (size_t)vd.rec_base * p.rec_stride);
         uint4 *rd = reinterpret_cast<uint4 *>(lds + p.par_rec_off);
-        for (uint32_t i = tid; i < vd.n_free * (kRecDwords / 4u); i += 256) rd[i] = rs[i];
+        for (uint32_t i = tid; i < vd.n_free * (p.rec_stride / 16u); i += 256) rd[i] = rs[i];
         for (uint32_t v = j; v < p.n_vars; v += 4) lds[v * kParStride + cb] = p.state[(size_t)v * p.pitch + chain];
         uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
         for (uint32_t i = tid; i < p.H; i += 256) h[i] = 0;
@@ -341,7 +341,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     const uint64_t q0 = (((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2;
     const uint32_t nq = p.n_steps >> 2; // multiple of 4
     const unsigned char *lds_c = lds + cb;
-    const uint32_t rec_bias = p.par_rec_off - vd.rec_base * (kRecDwords * 4u);
+    const uint32_t rec_bias = p.par_rec_off - vd.rec_base * p.rec_stride;
 
     // the block's scan plan (all 4 waves walk the same plan), staged per wave through an LDS ring
     const uint4 *gplan = reinterpret_cast<const uint4 *>(p.plan + (size_t)blockIdx.x * p.plan_pitch);
@@ -454,6 +454,10 @@ hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32
         case 4: return launch_par_t<4, true>(p, blocks, lds, s);
         case 5: return launch_par_t<5, true>(p, blocks, lds, s);
         case 6: return launch_par_t<6, true>(p, blocks, lds, s);
+        case 13: return launch_par_t<13, true>(p, blocks, lds, s); // 128-byte records (rec_stride = 128)
+        case 14: return launch_par_t<14, true>(p, blocks, lds, s);
+        case 15: return launch_par_t<15, true>(p, blocks, lds, s);
+        case 16: return launch_par_t<16, true>(p, blocks, lds, s);
         default: break;
         }
     switch (slots) {

@@ -28,3 +28,14 @@ if __name__ == "__main__":
     timing("Grids_13.uai", 65536, 200, g.GR_FLAG_DIRECT)
     timing("CSP_12.uai", 32768, 100)
     timing("Pedigree_11.uai", 32768, 50)
+    def timing_collapsed(name, nch, K, sweeps):
+        m = g.Model.NewModelFromFile(os.path.join(RES, name))
+        s = g.HIPChains(m, nch, n_variants=K)
+        for k in range(K):
+            s.Collapse(k, -1)
+        n = m.n_vars
+        s.BurnIn(n * 10)
+        s.Advance(n * sweeps)
+        i = s.info()
+        print(f"time {name} COLLAPSED chains={nch} groups={K} path={i['path']} lds={i['lds_bytes']}: {i['kernel_ms_last']:.2f} ms for {sweeps} sweeps -> {nch * n * sweeps / (i['kernel_ms_last'] * 1e-3):.3e} updates/s", flush=True)
+    timing_collapsed("Segmentation_11.uai", 32768, 128, 200)

@@ -190,3 +190,45 @@ def test_collapsed_sampling_matches_oracle(oracle, res_dir):
     # memoised and direct paths agree bit for bit on collapsed models too
     sd, cvd = gpu(42, g.GR_FLAG_DIRECT)
     assert cvd == cv and np.array_equal(sd.counts(), cnt)
+
+
+def test_collapsed_full_size_properties(res_dir):
+    """BASELINE config 3 at full size: Segmentation_11, 32 768 chains in 128 groups (the reference's
+    MaxChains, adaptive.go:49) of 256, each group with its own collapsed variable.  Size-independent
+    properties: conservation, determinism, memoised+planned fast path == direct path bit for bit,
+    collapsed variables carry their exact marginal through MergeChains."""
+    name = "Segmentation_11.uai"
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    pm = uai_py.load(res_dir, name)
+    n, K, cpv = len(pm.card), 128, 256
+    upd = 4 * n + 7
+
+    def run(flags=0):
+        s = g.HIPChains.NewGibbsCollapsed(gm, K * cpv, K, seed=11, flags=flags)
+        cvs, margs = [], []
+        for k in range(K):
+            v, mg = s.Collapse(k, -1)
+            cvs.append(v); margs.append(mg)
+        s.BurnIn(2 * n + 3)
+        s.Advance(upd)
+        return s, cvs, margs
+
+    a, cva, ma = run()
+    assert a.info()["path"] in (2, 3)  # the binary fast path handles per-group models
+    ca = a.counts()
+    assert int(ca.sum()) == K * cpv * upd == a.TotalSampleCount()
+    b, cvb, _ = run()
+    assert cvb == cva and np.array_equal(ca, b.counts())
+    d, cvd, _ = run(g.GR_FLAG_DIRECT)
+    assert d.info()["path"] == 0 and cvd == cva and np.array_equal(ca, d.counts())
+    merged, coll = g.MergeChains([a])
+    off = np.concatenate([[0], np.cumsum(pm.card)])
+    first = {}
+    for k, v in enumerate(cva):
+        assert ca[k, off[v]:off[v + 1]].sum() == 0
+        first.setdefault(v, ma[k])
+    for v, mg in first.items():
+        assert coll[v] == 1 and np.allclose(merged[v], mg, rtol=1e-15)
+    free_everywhere = [v for v in range(n) if v not in first]
+    v0 = free_everywhere[0]
+    assert merged[v0].sum() == pytest.approx(K * cpv + ca[:, off[v0]:off[v0 + 1]].sum(), rel=1e-12)
