@@ -33,7 +33,7 @@ $(OBJDIR)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) i
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS) -ldl -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -s -C oracle liboracle.so

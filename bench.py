@@ -86,7 +86,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # BENCH_FORCE_DIST=1 initialises the process group even for one rank (exercises RCCL on a 1-GPU box)
+    if world > 1 or os.environ.get("BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:

@@ -1,6 +1,7 @@
 // C-ABI implementation (include/grample_hip.h): host orchestration of the
 // gfx950 Gibbs kernels.  No CPU sampling path exists in this library.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 #include <rccl/rccl.h>
 
 #include <algorithm>
@@ -890,14 +891,24 @@ GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t 
             devs[i] = samplers[i]->o.device;
         }
         if (n > 1) {
+            // RCCL is bound lazily: a host process that brings its own RCCL (e.g. PyTorch) never sees a second copy
+            static void *h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+            if (!h) throw Error(GR_E_NO_DEVICE, std::string("cannot load librccl.so: ") + dlerror());
+            auto pInitAll = reinterpret_cast<ncclResult_t (*)(ncclComm_t *, int, const int *)>(dlsym(h, "ncclCommInitAll"));
+            auto pAllReduce = reinterpret_cast<ncclResult_t (*)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t)>(dlsym(h, "ncclAllReduce"));
+            auto pGroupStart = reinterpret_cast<ncclResult_t (*)()>(dlsym(h, "ncclGroupStart"));
+            auto pGroupEnd = reinterpret_cast<ncclResult_t (*)()>(dlsym(h, "ncclGroupEnd"));
+            auto pDestroy = reinterpret_cast<ncclResult_t (*)(ncclComm_t)>(dlsym(h, "ncclCommDestroy"));
+            if (!pInitAll || !pAllReduce || !pGroupStart || !pGroupEnd || !pDestroy) throw Error(GR_E_NO_DEVICE, "librccl.so lacks the expected symbols");
             std::vector<ncclComm_t> comms(n);
-            if (ncclCommInitAll(comms.data(), n, devs.data()) != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclCommInitAll failed");
-            ncclGroupStart();
+            if (pInitAll(comms.data(), n, devs.data()) != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclCommInitAll failed");
+            pGroupStart();
             for (int i = 0; i < n; ++i)
-                ncclAllReduce(samplers[i]->d_counts.p, samplers[i]->d_counts.p, cnt, ncclUint64, ncclSum, comms[i], samplers[i]->stream);
-            const ncclResult_t r = ncclGroupEnd();
+                pAllReduce(samplers[i]->d_counts.p, samplers[i]->d_counts.p, cnt, ncclUint64, ncclSum, comms[i], samplers[i]->stream);
+            const ncclResult_t r = pGroupEnd();
             for (int i = 0; i < n; ++i) { samplers[i]->use(); samplers[i]->sync(); }
-            for (int i = 0; i < n; ++i) ncclCommDestroy(comms[i]);
+            for (int i = 0; i < n; ++i) pDestroy(comms[i]);
             if (r != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclAllReduce failed");
         }
         if (out && gr_counts(samplers[0], out, nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
