@@ -60,6 +60,30 @@ def cpu_baseline(res_dir):
                       f"updates per chain, f64 + MT19937-64 per thread ({dt:.1f} s wall)"}
 
 
+def parity_probe(res_dir, g):
+    """Matched small run next to the headline number: the SAME chain count, burn-in and update count
+    on the oracle (MT19937-64, f64) and on the GPU (Philox, f32 tables), each scored against
+    Grids_13.uai.MAR with the reference's ErrorSuite, plus the Hellinger distance between the two
+    merged marginals.  (The seed-for-seed streams differ by construction -- DESIGN.md D5 -- so the
+    comparison is between estimators of the same law at the same horizon.)"""
+    import numpy as np
+    from oracle import pyoracle as O
+    from tests import uai_py
+    pm = uai_py.load(res_dir, MODEL)
+    sol = uai_py.load_mar(res_dir, MODEL)
+    chains, burn, upd = 512, 2000, 20000
+    mo, _, _, _ = O.run_chains(O.Model.from_parsed(pm), 42, chains, burn, upd)
+    s = g.HIPChains.NewGibbsSimple(g.Model.NewModelFromFile(os.path.join(res_dir, MODEL)), chains, seed=42)
+    s.BurnIn(burn)
+    s.Advance(upd)
+    mg, _ = g.MergeChains([s])
+    e_cpu, e_gpu, e_x = g.NewErrorSuite(pm.card, sol, mo), g.NewErrorSuite(pm.card, sol, mg), g.NewErrorSuite(pm.card, mo, mg)
+    return {"chains": chains, "burn_in": burn, "updates_per_chain": upd,
+            "cpu_oracle_vs_MAR": {"mean_hellinger": e_cpu["MeanHellinger"], "max_hellinger": e_cpu["MaxHellinger"], "mean_abs_err": e_cpu["MeanMeanAbsError"]},
+            "gpu_vs_MAR": {"mean_hellinger": e_gpu["MeanHellinger"], "max_hellinger": e_gpu["MaxHellinger"], "mean_abs_err": e_gpu["MeanMeanAbsError"]},
+            "gpu_vs_cpu_oracle": {"mean_hellinger": e_x["MeanHellinger"], "max_hellinger": e_x["MaxHellinger"], "mean_abs_err": e_x["MeanMeanAbsError"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -177,6 +201,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res_dir)
+            out["parity_probe"] = parity_probe(res_dir, g)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
