@@ -198,7 +198,11 @@ __device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, 
 //   CPT = true : conditionals memoised per (variable, blanket configuration)
 //                by k_build_cpt -- one table word per binary update.
 //   TAB_LDS    : tables staged in LDS (else read from global through L1/L2).
-template <int MAXC, bool CPT, bool TAB_LDS, bool PW>
+// PC (strict mode, GR_FLAG_SCAN_PER_CHAIN): every chain draws its own variable at every step, exactly like
+// UniformSampler.VarSample per chain (sampler.go:135-174); nothing is wave-uniform any more (divergent
+// program walks, per-lane histogram atomics).  Slow; exists so that the reference's exact process law is
+// available and the wave-uniform scan can be checked against it.
+template <int MAXC, bool CPT, bool TAB_LDS, bool PW, bool PC>
 __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t T = blockDim.x;
@@ -278,7 +282,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
         st[v * T] = (unsigned char)val;
         if (counting) {
             const uint32_t C = pg[0] & 0xffu, ho = pg[1];
-            if (C == 2) {
+            if (!PC && C == 2) {
                 const uint32_t ones = (uint32_t)__popcll(__ballot(active && val != 0));
                 if (lane == 0) {
                     hist[ho] += nact - ones;
@@ -293,7 +297,8 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
         // which variable each of the next 4 steps updates: wave-uniform stream -> SALU
-        const u32x4 sc = philox4x32_10(q_lo, q_hi, wave_gid, DOM_SCAN, p.seed_lo, p.seed_hi);
+        const u32x4 sc = PC ? philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_SCAN_CHAIN + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi)
+                            : philox4x32_10(q_lo, q_hi, wave_gid, DOM_SCAN, p.seed_lo, p.seed_hi);
         // the 4 categorical draws of this chain
         const u32x4 dr = philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
         const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w};
@@ -305,7 +310,9 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
         for (int j = 0; j < 4; ++j) {
             const uint64_t s = (q << 2) + j;
             valid[j] = (s >= step0) && (s < step1);
-            v[j] = freev[uni(mul_hi_u32(uni(su[j]), vd.n_free))]; // VarSample: uniform over the selectable variables
+            // VarSample: uniform over the selectable variables
+            if constexpr (PC) v[j] = freev[mul_hi_u32(su[j], vd.n_free)];
+            else v[j] = freev[uni(mul_hi_u32(uni(su[j]), vd.n_free))];
             pg[j] = progs + poff[v[j]];
         }
         // Phase A: conditionals of all 4 steps from the current state.  Step j's
@@ -484,20 +491,22 @@ __global__ void __launch_bounds__(256) k_collapse(const CollapseArgs a) {
         else { constexpr int MC = 64; __VA_ARGS__; }               \
     } while (0)
 
-template <int MC, bool CPT, bool TL, bool PW>
+template <int MC, bool CPT, bool TL, bool PW, bool PC = false>
 static hipError_t launch_sweep_t(const SweepParams &p, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<MC, CPT, TL, PW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<MC, CPT, TL, PW, PC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sweep<MC, CPT, TL, PW>), dim3(blocks), dim3(threads), lds, s, p);
+    hipLaunchKernelGGL((k_sweep<MC, CPT, TL, PW, PC>), dim3(blocks), dim3(threads), lds, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, uint32_t blocks, uint32_t threads,
-                        uint32_t lds_bytes, hipStream_t s) {
+hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, bool per_chain, uint32_t blocks,
+                        uint32_t threads, uint32_t lds_bytes, hipStream_t s) {
     hipError_t e = hipSuccess;
     GR_DISPATCH_MAXC(max_card, {
-        if (cpt) e = tab_lds ? launch_sweep_t<MC, true, true, false>(p, blocks, threads, lds_bytes, s)
+        if (per_chain) e = tab_lds ? launch_sweep_t<MC, false, true, false, true>(p, blocks, threads, lds_bytes, s)
+                                   : launch_sweep_t<MC, false, false, false, true>(p, blocks, threads, lds_bytes, s);
+        else if (cpt) e = tab_lds ? launch_sweep_t<MC, true, true, false>(p, blocks, threads, lds_bytes, s)
                              : launch_sweep_t<MC, true, false, false>(p, blocks, threads, lds_bytes, s);
         else if (pairwise) e = tab_lds ? launch_sweep_t<MC, false, true, true>(p, blocks, threads, lds_bytes, s)
                                        : launch_sweep_t<MC, false, false, true>(p, blocks, threads, lds_bytes, s);

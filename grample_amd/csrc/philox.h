@@ -26,6 +26,7 @@ enum : uint32_t {
     DOM_SCAN = 2,     // per wavefront, per 4 steps: which variable to update
     DOM_INIT = 3,     // per chain, per variable: start state
     DOM_COLLAPSE = 4, // per variant, per try: Collapse(-1) selection
+    DOM_SCAN_CHAIN = 5, // per chain, per 4 steps: which variable to update (strict mode GR_FLAG_SCAN_PER_CHAIN)
 };
 
 struct u32x4 {

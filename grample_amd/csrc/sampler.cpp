@@ -137,7 +137,7 @@ struct gr_sampler {
 void gr_sampler::configure() {
     cpv = o.n_chains / o.n_variants;
     uint32_t views_max = 0, cpt_max = 0;
-    bool all_cpt = !(o.flags & GR_FLAG_DIRECT);
+    bool all_cpt = !(o.flags & (GR_FLAG_DIRECT | GR_FLAG_SCAN_PER_CHAIN));
     for (const auto &im : image) {
         views_max = std::max<uint32_t>(views_max, (uint32_t)im.views.size());
         cpt_max = std::max<uint32_t>(cpt_max, (im.cpt_words + 3u) & ~3u);
@@ -380,7 +380,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
             p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
             p.n_steps = n;
-            hip_check(launch_sweep(p, max_card, cpt, tab_lds, pairwise, blocks, T, lds, stream), "k_sweep launch");
+            hip_check(launch_sweep(p, max_card, cpt, tab_lds, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, blocks, T, lds, stream), "k_sweep launch");
             step += n;
             left -= n;
             launches_last++;

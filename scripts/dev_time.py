@@ -39,3 +39,5 @@ if __name__ == "__main__":
         i = s.info()
         print(f"time {name} COLLAPSED chains={nch} groups={K} path={i['path']} lds={i['lds_bytes']}: {i['kernel_ms_last']:.2f} ms for {sweeps} sweeps -> {nch * n * sweeps / (i['kernel_ms_last'] * 1e-3):.3e} updates/s", flush=True)
     timing_collapsed("Segmentation_11.uai", 32768, 128, 200)
+    timing("Grids_13.uai", 65536, 100, g.GR_FLAG_SCAN_PER_CHAIN)
+    timing("ObjectDetection_13.uai", 32768, 30, g.GR_FLAG_SCAN_PER_CHAIN)

@@ -10,7 +10,7 @@ import numpy as np
 
 M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 W0, W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
-DOM_DRAW, DOM_SCAN, DOM_INIT = 1, 2, 3
+DOM_DRAW, DOM_SCAN, DOM_INIT, DOM_SCAN_CHAIN = 1, 2, 3, 5
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -57,7 +57,8 @@ class Emulator:
     thresholds(v, state_column) -> uint64 array of Card-1 cumulative thresholds.
     """
 
-    def __init__(self, card, fixed, free_vars, thresholds, n_chains, seed, chain_offset=0):
+    def __init__(self, card, fixed, free_vars, thresholds, n_chains, seed, chain_offset=0, per_chain=False):
+        self.per_chain = per_chain
         self.card, self.fixed = list(card), list(fixed)
         self.free = list(free_vars)
         self.thr = thresholds
@@ -74,8 +75,12 @@ class Emulator:
         for s in range(self.step, self.step + n_steps):
             q, j = s >> 2, s & 3
             ql, qh = np.uint32(q & 0xFFFFFFFF), np.uint32(q >> 32)
-            sc = philox4x32_10(np.full(self.n_chains, ql), np.full(self.n_chains, qh), wave,
-                               np.full(self.n_chains, DOM_SCAN, dtype=np.uint32), k0, k1)[j]
+            if self.per_chain:  # strict mode: the scan stream is keyed by the chain, not by its 64-chain group
+                sc = philox4x32_10(np.full(self.n_chains, ql), np.full(self.n_chains, qh), g.astype(np.uint32),
+                                   np.uint32(DOM_SCAN_CHAIN) + ((g >> np.uint64(32)).astype(np.uint32) << np.uint32(4)), k0, k1)[j]
+            else:
+                sc = philox4x32_10(np.full(self.n_chains, ql), np.full(self.n_chains, qh), wave,
+                                   np.full(self.n_chains, DOM_SCAN, dtype=np.uint32), k0, k1)[j]
             dr = philox4x32_10(np.full(self.n_chains, ql), np.full(self.n_chains, qh), g.astype(np.uint32),
                                np.uint32(DOM_DRAW) + ((g >> np.uint64(32)).astype(np.uint32) << np.uint32(4)), k0, k1)[j]
             ks = mul_hi(sc, len(self.free))

@@ -122,13 +122,17 @@ def _thresholds_from_device(s, cards):
     ("ObjectDetection_13.uai", False, 64, 41, 0),
     ("Pedigree_11.uai", True, 64, 61, 0),
     ("one.uai", False, 1, 64, 0),
+    ("Grids_11.uai", False, 128, 97, g.GR_FLAG_SCAN_PER_CHAIN),       # strict mode: per-chain variable draws
+    ("ObjectDetection_13.uai", False, 64, 33, g.GR_FLAG_SCAN_PER_CHAIN),
+    ("Pedigree_11.uai", True, 70, 45, g.GR_FLAG_SCAN_PER_CHAIN),
 ])
 def test_sweep_bitwise_vs_numpy_emulator(res_dir, name, ev, chains, steps, flags):
     pm = uai_py.load(res_dir, name, ev)
     off = 64 * 5 if chains % 64 == 0 else 0
     s = g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, name), ev), chains, seed=1234, chain_offset=off, flags=flags)
     free = [v for v in range(len(pm.card)) if pm.fixed[v] < 0]
-    em = Emulator(pm.card, pm.fixed, free, _thresholds_from_device(s, pm.card), chains, 1234, chain_offset=off)
+    em = Emulator(pm.card, pm.fixed, free, _thresholds_from_device(s, pm.card), chains, 1234, chain_offset=off,
+                  per_chain=bool(flags & g.GR_FLAG_SCAN_PER_CHAIN))
     for c in (0, chains - 1):  # start state (gibbs-simple.go:84-112)
         assert np.array_equal(s.LastSample(c), em.state[:, c])
     burn = 13
@@ -364,3 +368,21 @@ def test_bench_two_ranks_rehearsal():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["chains_total"] == 2 * 65536 and d["value"] > 1e9
     assert d["scaling"] == "weak" and "cpu_baseline" not in d
+
+
+@pytest.mark.parametrize("name,sweeps", [("Grids_11.uai", 40), ("ObjectDetection_13.uai", 40)])
+def test_group_scan_equals_per_chain_scan_in_law(res_dir, name, sweeps):
+    """sharing the scan variable inside a 64-chain group (default) must estimate the same
+    marginals as the strict mode where every chain draws its own variable like the reference does.
+    Two-sample z-test over G groups, as in test_marginals_match_oracle_runs."""
+    pm = uai_py.load(res_dir, name)
+    n, G = len(pm.card), 32
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    ps = []
+    for flags, seed in ((0, 5), (g.GR_FLAG_SCAN_PER_CHAIN, 6)):
+        s = g.HIPChains(m, G * 64, n_variants=G, seed=seed, flags=flags)
+        s.BurnIn(10 * n); s.Advance(sweeps * n)
+        ps.append(_group_props(s.counts(), pm.card))
+    se = np.sqrt(ps[0].var(axis=0, ddof=1) / G + ps[1].var(axis=0, ddof=1) / G)
+    z = (ps[0].mean(axis=0) - ps[1].mean(axis=0)) / np.maximum(se, 2e-4)
+    assert np.max(np.abs(z)) <= 5.5 and np.mean(z ** 2) <= 2.0, (np.max(np.abs(z)), np.mean(z ** 2))
