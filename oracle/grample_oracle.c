@@ -722,15 +722,47 @@ ORC_API int orc_collapsed_sample(orc_collapsed *g, int *s, int slen) {
     return simple_sample_var(g->base, v, s, NULL);
 }
 
+/* ------------------------------------------------------------ CircularInt
+ * buffer/circular.go:1-102: ring of the last BufSize ints, iterable as an older
+ * and a newer half. */
+typedef struct { int *buffer; int pos, buf_size, count; int64_t total_seen; } orc_ring;
+
+ORC_API orc_ring *orc_ring_new(int total_size) { /* circular.go:16-28: odd sizes are rounded down */
+    orc_ring *r = (orc_ring *)calloc(1, sizeof *r);
+    int half = total_size / 2;
+    r->buf_size = half + half;
+    r->buffer = (int *)calloc(r->buf_size > 0 ? r->buf_size : 1, sizeof(int));
+    return r;
+}
+ORC_API void orc_ring_free(orc_ring *r) { if (r) { free(r->buffer); free(r); } }
+ORC_API void orc_ring_add(orc_ring *r, int v) { /* circular.go:36-49 (a zero-sized ring would panic in Go; here it only counts) */
+    r->total_seen++;
+    if (r->buf_size < 1) return;
+    r->buffer[r->pos] = v;
+    r->pos = (r->pos + 1) % r->buf_size;
+    r->count++;
+    if (r->count > r->buf_size) r->count = r->buf_size;
+}
+/* circular.go:54-84: copies the older (which=0) or newer (which=1) half into out[buf_size/2];
+ * returns the number of values or -1 while the ring is not full (Go returns a nil iterator) */
+ORC_API int orc_ring_half(const orc_ring *r, int which, int *out) {
+    if (r->count < r->buf_size || r->buf_size < 1) return -1;
+    int half = r->buf_size / 2;
+    int cur = which ? (r->pos + half) % r->buf_size : r->pos;
+    for (int i = 0; i < half; i++) { out[i] = r->buffer[cur]; cur = (cur + 1) % r->buf_size; }
+    return half;
+}
+ORC_API int orc_ring_buf_size(const orc_ring *r) { return r->buf_size; }
+ORC_API int orc_ring_count(const orc_ring *r) { return r->count; }
+
 /* ------------------------------------------------------------------- Chain
- * sampler/chain.go.  The ring buffer ChainHistory (buffer/circular.go) feeds
- * only convergence diagnostics (out of scope); its TotalSeen counter is what
- * AdvanceChain's stopping rule reads, so that is what is kept here. */
+ * sampler/chain.go */
 typedef struct {
     orc_model *target;       /* not owned */
     orc_simple *simple;      /* exactly one of simple / collapsed is set */
     orc_collapsed *coll;
     int cw;
+    orc_ring **history;      /* ChainHistory: one ring of cw values per variable (chain.go:156-164) */
     int64_t *total_seen;
     int64_t total_sample_count;
     int *last_sample;
@@ -746,6 +778,7 @@ static int chain_one_sample(orc_chain *c, int update_vars) {
         int value = c->last_sample[idx];
         orc_var *v = &c->target->vars[idx];
         if (!v->collapsed) v->marginal[value] += 1.0;
+        orc_ring_add(c->history[idx], value); /* chain.go:238 */
         c->total_seen[idx]++;
         c->total_sample_count++;
     }
@@ -757,6 +790,8 @@ static orc_chain *chain_new(orc_model *m, orc_simple *s, orc_collapsed *g, int c
     c->target = m; c->simple = s; c->coll = g; c->cw = cw;
     c->total_seen = (int64_t *)calloc(m->nvars, sizeof(int64_t));
     c->last_sample = (int *)calloc(m->nvars, sizeof(int));
+    c->history = (orc_ring **)calloc(m->nvars, sizeof(orc_ring *));
+    for (int i = 0; i < m->nvars; i++) c->history[i] = orc_ring_new(cw);
     for (int64_t i = 0; i < burn_in; i++)
         if (chain_one_sample(c, 0)) { orc_fail("Failure during chain burn in"); return NULL; }
     return c;
@@ -764,7 +799,11 @@ static orc_chain *chain_new(orc_model *m, orc_simple *s, orc_collapsed *g, int c
 ORC_API orc_chain *orc_chain_new_simple(orc_model *m, orc_simple *s, int cw, int64_t burn_in) { return chain_new(m, s, NULL, cw, burn_in); }
 ORC_API orc_chain *orc_chain_new_collapsed(orc_model *m, orc_collapsed *g, int cw, int64_t burn_in) { return chain_new(m, NULL, g, cw, burn_in); }
 ORC_API orc_chain *orc_chain_new_nosampler(orc_model *m) { return chain_new(m, NULL, NULL, 0, 0); } /* chain_test.go:32 */
-ORC_API void orc_chain_free(orc_chain *c) { if (c) { free(c->total_seen); free(c->last_sample); free(c); } }
+ORC_API void orc_chain_free(orc_chain *c) {
+    if (!c) return;
+    if (c->history) for (int i = 0; i < c->target->nvars; i++) orc_ring_free(c->history[i]);
+    free(c->history); free(c->total_seen); free(c->last_sample); free(c);
+}
 ORC_API int64_t orc_chain_total_samples(const orc_chain *c) { return c->total_sample_count; }
 ORC_API void orc_chain_get_last(const orc_chain *c, int *out) { memcpy(out, c->last_sample, sizeof(int) * c->target->nvars); }
 
@@ -895,6 +934,186 @@ ORC_API int orc_error_suite(int nvars, const int *card1, const int *card2, const
     }
     for (int k = 0; k < 4; k++) out[k] /= (double)count;
     return 0;
+}
+
+/* --------------------------------------------------------- ChainConvergence
+ * sampler/chain.go:32-92, 253-290.  measure: 0 Hellinger, 1 JS, 2 MaxAbs, 3 MeanAbs. */
+static double measure_fn(int measure, const double *a, const double *b, int card) {
+    switch (measure) {
+    case 1: return orc_js_divergence(a, b, card);
+    case 2: return orc_max_abs_diff(a, b, card);
+    case 3: return orc_mean_abs_diff(a, b, card);
+    default: return orc_hellinger(a, b, card);
+    }
+}
+/* chain.go:253-290 ChainDist: within = d(first half, second half), between = d(merged, first + second) */
+static int chain_dist(const orc_chain *c, int measure, int v, const double *merged, int merged_card, double *within, double *between) {
+    const orc_ring *hist = c->history[v];
+    if (hist->total_seen < (int64_t)c->cw) return orc_fail("Total seen < Convergence Window");
+    int card = c->target->vars[v].card;
+    if (card != merged_card) return orc_fail("Variable mismatch");
+    double *v1 = (double *)malloc(sizeof(double) * card * 2), *v2 = v1 + card;
+    for (int i = 0; i < card; i++) v1[i] = v2[i] = 1e-8;
+    int half = hist->buf_size / 2;
+    int *tmp = (int *)malloc(sizeof(int) * (half > 0 ? half : 1));
+    int n1 = orc_ring_half(hist, 0, tmp);
+    for (int i = 0; i < n1; i++) v1[tmp[i]] += 1.0;
+    int n2 = orc_ring_half(hist, 1, tmp);
+    for (int i = 0; i < n2; i++) v2[tmp[i]] += 1.0;
+    free(tmp);
+    if (n1 < 0 || n2 < 0) { free(v1); return orc_fail("history ring not full (Go: nil iterator)"); }
+    *within = measure_fn(measure, v1, v2, card);
+    for (int i = 0; i < card; i++) v1[i] += v2[i];
+    *between = measure_fn(measure, merged, v1, card);
+    free(v1);
+    return 0;
+}
+/* chain.go:32-92.  merged / merged_collapsed may be NULL (then MergeChains is called). out[nvars]. */
+ORC_API int orc_chain_convergence(orc_chain **chains, int n, int measure, const double *merged, const int *merged_collapsed, double *out) {
+    if (n < 2) return orc_fail("Convergence requires at least 2 chains");
+    int nv = chains[0]->target->nvars, tot = 0;
+    for (int v = 0; v < nv; v++) tot += chains[0]->target->vars[v].card;
+    double *mm = NULL; int *mc = NULL;
+    if (!merged) {
+        mm = (double *)malloc(sizeof(double) * tot); mc = (int *)malloc(sizeof(int) * nv);
+        if (orc_merge_chains(chains, n, mm, mc)) { free(mm); free(mc); return -1; }
+        merged = mm; merged_collapsed = mc;
+    }
+    double sample_count = (double)chains[0]->cw, chain_count = (double)n;
+    double b_norm = sample_count / (chain_count - 1);
+    double w_factor = (sample_count - 1) / sample_count;
+    double b_factor = (chain_count + 1) / (chain_count * sample_count);
+    int off = 0, rc = 0;
+    for (int i = 0; i < nv && !rc; i++) {
+        int card = chains[0]->target->vars[i].card;
+        if ((merged_collapsed && merged_collapsed[i]) || chains[0]->target->vars[i].fixed_val >= 0) { out[i] = 1.0; off += card; continue; }
+        double W = 1e-8, B = 1e-8;
+        for (int c = 0; c < n; c++) {
+            double w1, b1;
+            if (chain_dist(chains[c], measure, i, merged + off, card, &w1, &b1)) { rc = -1; break; }
+            W += w1; B += b1;
+        }
+        W /= chain_count;
+        B *= b_norm;
+        double vhat = (w_factor * W) + (b_factor * B);
+        out[i] = sqrt((4.0 * vhat) / (2.0 * W));
+        off += card;
+    }
+    free(mm); free(mc);
+    return rc;
+}
+
+/* ---------------------------------------------------------------- ensemble
+ * What cmd/root.go:373-430 builds for `--sampler adaptive` plus ConvergenceSampler.Adapt
+ * (sampler/adaptive.go:57-157).  Owns the generator, the base model and every chain. */
+#define ORC_MAX_CHAINS 128 /* adaptive.go:49 */
+typedef struct {
+    orc_gen *gen; orc_model *base;
+    int n, cap;
+    orc_chain **ch; orc_model **mods; orc_collapsed **cs;
+} orc_ensemble;
+
+static int ensemble_push(orc_ensemble *e, orc_model *m, orc_collapsed *g, orc_chain *c) {
+    if (e->n == e->cap) {
+        e->cap = e->cap ? e->cap * 2 : 8;
+        e->ch = (orc_chain **)realloc(e->ch, sizeof(*e->ch) * e->cap);
+        e->mods = (orc_model **)realloc(e->mods, sizeof(*e->mods) * e->cap);
+        e->cs = (orc_collapsed **)realloc(e->cs, sizeof(*e->cs) * e->cap);
+    }
+    e->ch[e->n] = c; e->mods[e->n] = m; e->cs[e->n] = g; e->n++;
+    return 0;
+}
+/* root.go:408-415 + 422: NewGibbsCollapsed without a collapse, NewChain(cw, burn-in) for every base chain */
+ORC_API orc_ensemble *orc_ensemble_new(const orc_model *base, int64_t seed, int n_base, int cw, int64_t burn_in) {
+    orc_ensemble *e = (orc_ensemble *)calloc(1, sizeof *e);
+    e->gen = orc_gen_new(seed);
+    e->base = orc_model_clone(base);
+    for (int c = 0; c < n_base; c++) {
+        orc_model *m = orc_model_clone(base);
+        orc_collapsed *g = orc_collapsed_new(e->gen, m);
+        orc_chain *ch = g ? orc_chain_new_collapsed(m, g, cw, burn_in) : NULL;
+        if (!ch) return NULL;
+        ensemble_push(e, m, g, ch);
+    }
+    return e;
+}
+ORC_API void orc_ensemble_free(orc_ensemble *e) {
+    if (!e) return;
+    for (int c = 0; c < e->n; c++) { orc_chain_free(e->ch[c]); orc_collapsed_free(e->cs[c]); orc_model_free(e->mods[c]); }
+    free(e->ch); free(e->mods); free(e->cs); orc_model_free(e->base); orc_gen_free(e->gen); free(e);
+}
+ORC_API int orc_ensemble_n(const orc_ensemble *e) { return e->n; }
+ORC_API orc_chain *orc_ensemble_chain(orc_ensemble *e, int i) { return e->ch[i]; }
+ORC_API int orc_ensemble_advance(orc_ensemble *e) { /* root.go:476-479 */
+    for (int c = 0; c < e->n; c++) if (orc_chain_advance(e->ch[c])) return -1;
+    return 0;
+}
+ORC_API int orc_ensemble_run(orc_ensemble *e, int64_t updates) {
+    for (int c = 0; c < e->n; c++) if (orc_chain_run(e->ch[c], updates)) return -1;
+    return 0;
+}
+ORC_API int orc_ensemble_merge(orc_ensemble *e, double *out_marginal, int *out_collapsed) { return orc_merge_chains(e->ch, e->n, out_marginal, out_collapsed); }
+ORC_API int orc_ensemble_convergence(orc_ensemble *e, int measure, double *out) { return orc_chain_convergence(e->ch, e->n, measure, NULL, NULL, out); }
+
+/* adaptive.go:57-157 Adapt.  out_vars[<= new_chain_count] receives the collapsed variable of every chain added;
+ * out_converge[nvars] (may be NULL) the scores used for ranking (NaN when ranking was not needed).
+ * Ranking: the reference sorts descending with sort.Slice (not stable) and takes from the TAIL, i.e. the
+ * lowest scores; ties are broken here by descending variable id at the tail (= ascending id picked last). */
+ORC_API int orc_ensemble_adapt(orc_ensemble *e, int new_chain_count, int *out_vars, int *out_n, double *out_converge) {
+    *out_n = 0;
+    int nv = e->base->nvars;
+    if (out_converge) for (int v = 0; v < nv; v++) out_converge[v] = NAN;
+    if (e->n < 2) return orc_fail("At least 2 chains required for adaptation");
+    if (e->n >= ORC_MAX_CHAINS) return 0;
+    orc_model *mod_clone = orc_model_clone(e->base);
+    orc_collapsed *samp = orc_collapsed_new(e->gen, mod_clone);
+    if (!samp) return -1;
+    int tot = 0; for (int v = 0; v < nv; v++) tot += e->base->vars[v].card;
+    double *merged = (double *)malloc(sizeof(double) * tot);
+    int *mcoll = (int *)malloc(sizeof(int) * nv);
+    int rc = orc_merge_chains(e->ch, e->n, merged, mcoll);
+    int *vars = (int *)malloc(sizeof(int) * nv), nvars = 0;
+    for (int v = 0; v < nv && !rc; v++) {
+        int sz = orc_collapsed_blanket_size(samp, v);
+        if (e->base->vars[v].fixed_val < 0 && !mcoll[v] && sz > 1 && sz <= ORC_NEIGHBOR_VAR_MAX) vars[nvars++] = v;
+    }
+    int *targets = (int *)malloc(sizeof(int) * (new_chain_count > 0 ? new_chain_count : 1)), nt = 0;
+    if (!rc && nvars >= 1) {
+        if (nvars <= new_chain_count) {
+            for (int i = 0; i < nvars; i++) targets[nt++] = vars[i];
+        } else {
+            double *conv = (double *)malloc(sizeof(double) * nv);
+            rc = orc_chain_convergence(e->ch, e->n, 0, merged, mcoll, conv);
+            if (!rc) {
+                if (out_converge) memcpy(out_converge, conv, sizeof(double) * nv);
+                /* descending by score (insertion sort, stable); then take from the tail */
+                for (int i = 1; i < nvars; i++) {
+                    int x = vars[i], j = i - 1;
+                    while (j >= 0 && conv[vars[j]] < conv[x]) { vars[j + 1] = vars[j]; j--; }
+                    vars[j + 1] = x;
+                }
+                for (int cc = 0, pos = nvars - 1; cc < new_chain_count; cc++, pos--) targets[nt++] = vars[pos];
+            }
+            free(conv);
+        }
+    }
+    const orc_chain *last = e->ch[e->n - 1];
+    for (int i = 0; i < nt && !rc; i++) { /* adaptive.go:131-153 */
+        if (!samp) {
+            mod_clone = orc_model_clone(e->base);
+            samp = orc_collapsed_new(e->gen, mod_clone);
+            if (!samp) { rc = -1; break; }
+        }
+        if (orc_collapsed_collapse(samp, targets[i]) < 0) { rc = -1; break; }
+        orc_chain *nc = orc_chain_new_collapsed(mod_clone, samp, last->cw, 2);
+        if (!nc) { rc = -1; break; }
+        ensemble_push(e, mod_clone, samp, nc);
+        out_vars[(*out_n)++] = targets[i];
+        samp = NULL; mod_clone = NULL;
+    }
+    if (samp) { orc_collapsed_free(samp); orc_model_free(mod_clone); }
+    free(merged); free(mcoll); free(vars); free(targets);
+    return rc;
 }
 
 /* ------------------------------------------------- multi-chain convenience

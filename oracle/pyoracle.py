@@ -98,6 +98,22 @@ def lib():
     sig("orc_chain_advance", i32, vp)
     sig("orc_chain_run", i32, vp, i64)
     sig("orc_merge_chains", i32, C.POINTER(vp), i32, pd, pi)
+    sig("orc_ring_new", vp, i32)
+    sig("orc_ring_free", None, vp)
+    sig("orc_ring_add", None, vp, i32)
+    sig("orc_ring_half", i32, vp, i32, pi)
+    sig("orc_ring_buf_size", i32, vp)
+    sig("orc_ring_count", i32, vp)
+    sig("orc_chain_convergence", i32, C.POINTER(vp), i32, i32, pd, pi, pd)
+    sig("orc_ensemble_new", vp, vp, i64, i32, i32, i64)
+    sig("orc_ensemble_free", None, vp)
+    sig("orc_ensemble_n", i32, vp)
+    sig("orc_ensemble_chain", vp, vp, i32)
+    sig("orc_ensemble_advance", i32, vp)
+    sig("orc_ensemble_run", i32, vp, i64)
+    sig("orc_ensemble_merge", i32, vp, pd, pi)
+    sig("orc_ensemble_convergence", i32, vp, i32, pd)
+    sig("orc_ensemble_adapt", i32, vp, i32, pi, pi, pd)
     sig("orc_max_abs_diff", dbl, pd, pd, i32)
     sig("orc_mean_abs_diff", dbl, pd, pd, i32)
     sig("orc_hellinger", dbl, pd, pd, i32)

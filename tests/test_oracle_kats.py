@@ -496,3 +496,125 @@ def test_oracle_reproduces_committed_vectors(oracle):
     assert got == want
     assert [float(x) for x in want["mt_seed42_float64"]] == [0.55853149089588316, 0.73629461442040611, 0.39337113195856088]
     assert want["one_uai_seed42_1024_draws_no_init"] == [255, 769]
+
+
+# ------------------------------------------------- buffer / convergence / adapt
+def test_circular_int(oracle):
+    """buffer/circular_test.go:9-60 TestCircularInt."""
+    L = oracle.lib()
+    r = L.orc_ring_new(6)
+    assert L.orc_ring_buf_size(r) == 6 and L.orc_ring_count(r) == 0
+    buf = np.zeros(3, dtype=np.int32)
+    for v in (1, 2, 3, 4, 5):
+        L.orc_ring_add(r, v)
+    assert L.orc_ring_count(r) == 5
+    assert L.orc_ring_half(r, 0, _ip(buf)) < 0 and L.orc_ring_half(r, 1, _ip(buf)) < 0  # nil iterators until full
+    L.orc_ring_add(r, 6)
+    assert L.orc_ring_count(r) == 6
+    assert L.orc_ring_half(r, 0, _ip(buf)) == 3 and buf.tolist() == [1, 2, 3]
+    assert L.orc_ring_half(r, 1, _ip(buf)) == 3 and buf.tolist() == [4, 5, 6]
+    L.orc_ring_add(r, 8); L.orc_ring_add(r, 8)
+    assert L.orc_ring_half(r, 0, _ip(buf)) == 3 and buf.tolist() == [3, 4, 5]
+    assert L.orc_ring_half(r, 1, _ip(buf)) == 3 and buf.tolist() == [6, 8, 8]
+    L.orc_ring_free(r)
+    r = L.orc_ring_new(7)  # odd sizes are rounded down (circular.go:18-20)
+    assert L.orc_ring_buf_size(r) == 6
+    L.orc_ring_free(r)
+
+
+def _conv_by_hand(first, second, merged, fixed, collapsed, cw, hell):
+    """chain.go:32-92 + 253-290 re-derived with numpy for a cross-check of the C restatement."""
+    m, nv = len(first), len(merged)
+    out = []
+    for i in range(nv):
+        if collapsed[i] or fixed[i] >= 0:
+            out.append(1.0)
+            continue
+        W = B = 1e-8
+        for c in range(m):
+            v1, v2 = first[c][i] + 1e-8, second[c][i] + 1e-8
+            W += hell(v1, v2)
+            B += hell(merged[i], v1 + v2)
+        W /= m
+        B *= cw / (m - 1)
+        vhat = (cw - 1) / cw * W + (m + 1) / (m * cw) * B
+        out.append(math.sqrt(4 * vhat / (2 * W)))
+    return out
+
+
+def test_chain_convergence_formula(oracle, res_dir):
+    """sampler/chain.go:32-92 ChainConvergence on real chains == an independent numpy evaluation of the
+    same formula from the chains' ring halves; fewer than 2 chains is an error; collapsed/fixed -> 1.0."""
+    L = oracle.lib()
+    pm = uai_py.load(res_dir, "Grids_11.uai")
+    base = oracle.Model.from_parsed(pm)
+    cw = 40
+    e = L.orc_ensemble_new(base.ptr, 42, 3, cw, 500)
+    assert e and L.orc_ensemble_n(e) == 3
+    assert L.orc_ensemble_advance(e) == 0  # AdvanceChain: every variable seen cw+1 more times
+    nv, tot = 100, 200
+    conv = np.zeros(nv)
+    assert L.orc_ensemble_convergence(e, 0, _dp(conv)) == 0
+    merged = np.zeros(tot); coll = np.zeros(nv, dtype=np.int32)
+    assert L.orc_ensemble_merge(e, _dp(merged), _ip(coll)) == 0
+    # rebuild the halves from the exported rings
+    first, second = [], []
+    half = cw // 2
+    tmp = np.zeros(half, dtype=np.int32)
+    import ctypes as Cc
+    class Chain(Cc.Structure):
+        _fields_ = [("target", Cc.c_void_p), ("simple", Cc.c_void_p), ("coll", Cc.c_void_p), ("cw", Cc.c_int),
+                    ("history", Cc.POINTER(Cc.c_void_p))]
+    for c in range(3):
+        ch = Cc.cast(L.orc_ensemble_chain(e, c), Cc.POINTER(Chain)).contents
+        f, s2 = [], []
+        for v in range(nv):
+            ring = ch.history[v]
+            assert L.orc_ring_half(ring, 0, _ip(tmp)) == half
+            f.append(np.bincount(tmp, minlength=2).astype(float))
+            assert L.orc_ring_half(ring, 1, _ip(tmp)) == half
+            s2.append(np.bincount(tmp, minlength=2).astype(float))
+        first.append(f); second.append(s2)
+    hell = lambda a, b: float(L.orc_hellinger(_dp(np.ascontiguousarray(a)), _dp(np.ascontiguousarray(b)), 2))
+    exp = _conv_by_hand(first, second, [merged[2 * v:2 * v + 2] for v in range(nv)], pm.fixed, coll, cw, hell)
+    assert np.allclose(conv, exp, rtol=1e-12)
+    assert np.all(conv > 0) and np.all(np.isfinite(conv))
+    arr = (Cc.c_void_p * 1)(L.orc_ensemble_chain(e, 0))
+    assert L.orc_chain_convergence(arr, 1, 0, None, None, _dp(conv)) != 0  # needs >= 2 chains
+    L.orc_ensemble_free(e)
+
+
+def test_adapt_policy(oracle, res_dir):
+    """sampler/adaptive.go:57-157: eligibility (free, not collapsed, blanket 2..12), ranking by ChainConvergence
+    and picking from the tail of the descending order, one new chain per target with that variable collapsed,
+    nothing once MaxChains (128) is reached, error below 2 chains."""
+    L = oracle.lib()
+    pm = uai_py.load(res_dir, "Grids_11.uai")
+    base = oracle.Model.from_parsed(pm)
+    e = L.orc_ensemble_new(base.ptr, 42, 2, 40, 500)
+    assert L.orc_ensemble_advance(e) == 0
+    out_vars = np.zeros(8, dtype=np.int32); n_out = C.c_int(); conv = np.zeros(100)
+    assert L.orc_ensemble_adapt(e, 4, _ip(out_vars), C.byref(n_out), _dp(conv)) == 0
+    assert n_out.value == 4 and L.orc_ensemble_n(e) == 6
+    picked = out_vars[:4].tolist()
+    order = sorted(range(100), key=lambda v: (-conv[v], v))  # descending score, stable
+    assert picked == order[::-1][:4]  # taken from the tail: the LOWEST scores (adaptive.go:111-119)
+    merged = np.zeros(200); coll = np.zeros(100, dtype=np.int32)
+    assert L.orc_ensemble_merge(e, _dp(merged), _ip(coll)) == 0
+    assert sorted(np.where(coll)[0].tolist()) == sorted(picked)
+    # second round: already collapsed variables are no longer eligible
+    assert L.orc_ensemble_advance(e) == 0
+    assert L.orc_ensemble_adapt(e, 4, _ip(out_vars), C.byref(n_out), _dp(conv)) == 0
+    assert n_out.value == 4 and not set(out_vars[:4].tolist()) & set(picked)
+    L.orc_ensemble_free(e)
+    e1 = L.orc_ensemble_new(base.ptr, 42, 1, 40, 100)
+    assert L.orc_ensemble_adapt(e1, 1, _ip(out_vars), C.byref(n_out), None) != 0  # at least 2 chains
+    L.orc_ensemble_free(e1)
+    # fewer candidates than slots: all of them, no ranking (sample.uai: vars 0,1,2 with blankets 2,3,2)
+    small = oracle.Model.from_parsed(uai_py.load(res_dir, "sample.uai"))
+    e2 = L.orc_ensemble_new(small.ptr, 42, 2, 20, 50)
+    assert L.orc_ensemble_advance(e2) == 0
+    assert L.orc_ensemble_adapt(e2, 5, _ip(out_vars), C.byref(n_out), _dp(conv)) == 0
+    assert n_out.value == 3 and sorted(out_vars[:3].tolist()) == [0, 1, 2] and L.orc_ensemble_n(e2) == 5
+    assert np.all(np.isnan(conv[:3]))  # no ranking was needed
+    L.orc_ensemble_free(e2)
