@@ -75,6 +75,12 @@ SIGNATURES = {
     "gr_set_state": (C.c_int, [vp, u32, pi32]),
     "gr_conditional": (C.c_int, [vp, u32, i32, pi32, pd]),
     "gr_sampler_get_info": (C.c_int, [vp, C.POINTER(SamplerInfo)]),
+    "gr_set_active_groups": (C.c_int, [vp, u32]),
+    "gr_active_groups": (C.c_int, [vp]),
+    "gr_advance_window": (C.c_int, [vp, u64]),
+    "gr_chain_convergence": (C.c_int, [i32, i32, pi32, pi32, pi32, pd, pd, pd, dbl, i32, pd]),
+    "gr_adapt_select": (C.c_int, [vp, pi32, pd, u32, pi32, pu32]),
+    "gr_adapt": (C.c_int, [vp, u32, pi32, pu32, pd]),
     "gr_philox4x32_10": (None, [pu32, pu32, pu32]),
 }
 

@@ -242,6 +242,23 @@ class HIPChains:
     def FunctionCount(self, variant, v):
         return self.L.gr_function_count(self.ptr, variant, v)
 
+    def set_active_groups(self, n):
+        _chk(self.L.gr_set_active_groups(self.ptr, n))
+
+    def active_groups(self):
+        return self.L.gr_active_groups(self.ptr)
+
+    def AdvanceWindow(self, updates_per_chain):
+        _chk(self.L.gr_advance_window(self.ptr, updates_per_chain))
+
+    def Adapt(self, newChainCount):
+        """ConvergenceSampler.Adapt: returns (collapsed variables of the groups added, convergence scores or NaNs)."""
+        out = np.zeros(max(newChainCount, 1), dtype=np.int32)
+        n = C.c_uint32()
+        conv = np.zeros(self.n_vars)
+        _chk(self.L.gr_adapt(self.ptr, newChainCount, _p(out, C.c_int32), C.byref(n), _p(conv, C.c_double)))
+        return out[: n.value].tolist(), conv
+
     def BurnIn(self, updates_per_chain):
         _chk(self.L.gr_burnin(self.ptr, updates_per_chain))
 
@@ -293,6 +310,31 @@ class HIPChains:
         i.struct_size = C.sizeof(SamplerInfo)
         _chk(self.L.gr_sampler_get_info(self.ptr, C.byref(i)))
         return {k: getattr(i, k) for k, _ in SamplerInfo._fields_ if k != "struct_size"}
+
+
+def ChainConvergence(cards, fixed, merged_collapsed, first, second, merged, cw, measure=0):
+    """sampler.ChainConvergence (chain.go:32-92) as a pure function of the half-window histograms.
+    first/second: [n_groups][total_card] arrays; merged: flat [total_card]."""
+    c = _i32(cards)
+    f = _i32(fixed) if fixed is not None else None
+    mc = _i32(merged_collapsed) if merged_collapsed is not None else None
+    a, b, m = _f64(first), _f64(second), _f64(merged)
+    out = np.zeros(len(c))
+    _chk(_lib.lib().gr_chain_convergence(a.shape[0], len(c), _p(c, C.c_int32), _p(f, C.c_int32) if f is not None else None,
+                                         _p(mc, C.c_int32) if mc is not None else None, _p(a, C.c_double), _p(b, C.c_double),
+                                         _p(m, C.c_double), float(cw), measure, _p(out, C.c_double)))
+    return out
+
+
+def AdaptSelect(model, merged_collapsed, converge, new_chain_count):
+    """The selection rule of ConvergenceSampler.Adapt (adaptive.go:78-119)."""
+    mc = _i32(merged_collapsed)
+    cv = _f64(converge) if converge is not None else None
+    out = np.zeros(max(new_chain_count, 1), dtype=np.int32)
+    n = C.c_uint32()
+    _chk(_lib.lib().gr_adapt_select(model.ptr, _p(mc, C.c_int32), _p(cv, C.c_double) if cv is not None else None,
+                                    new_chain_count, _p(out, C.c_int32), C.byref(n)))
+    return out[: n.value].tolist()
 
 
 def MergeChains(samplers):

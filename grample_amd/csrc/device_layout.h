@@ -35,7 +35,8 @@ struct SweepParams {
     unsigned long long *counts; // [n_variants][H]
     uint32_t n_vars;
     uint32_t H;                 // sum of Card
-    uint32_t n_chains;          // chains on this device
+    uint32_t chain0;            // first local chain of this launch (multiple of the block size)
+    uint32_t n_chains;          // one past the last local chain of this launch
     uint32_t pitch;             // row pitch of state (chains rounded up to 256)
     uint32_t chains_per_variant;
     uint32_t chain_offset_lo, chain_offset_hi; // global id of local chain 0 (multiple of 64)

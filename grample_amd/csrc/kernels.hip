@@ -209,9 +209,9 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
-    const uint32_t chain = blockIdx.x * T + tid; // local chain index
+    const uint32_t chain = p.chain0 + blockIdx.x * T + tid; // local chain index
     const bool active = chain < p.n_chains;
-    const uint32_t variant = (blockIdx.x * T) / p.chains_per_variant; // blocks never straddle groups
+    const uint32_t variant = (p.chain0 + blockIdx.x * T) / p.chains_per_variant; // blocks never straddle groups
     const VariantDesc vd = p.variants[variant];
 
     unsigned char *st = lds + tid;                                    // st[var * T]

@@ -116,6 +116,13 @@ struct gr_sampler {
     DevBuf<unsigned long long> d_counts;
     std::vector<VariantDesc> h_variants;
     uint64_t step = 0, counted = 0;
+    // adaptive sampler (N2): groups [0, n_active) run; the rest wait to be activated by gr_adapt
+    uint32_t n_active = 0;
+    std::vector<uint64_t> counted_g;             // counted updates per chain, per group
+    std::vector<double> win_first, win_second;   // [n_variants * H] halves of the last convergence window
+    double win_cw = 0;
+    Model base_linear;                           // the caller's model as given (linear tables): Adapt clones it
+    uint32_t active_chains() const { return o.n_variants > 1 ? n_active * (o.n_chains / o.n_variants) : o.n_chains; }
     double kernel_ms_last = 0;
     uint32_t launches_last = 0;
 
@@ -131,6 +138,7 @@ struct gr_sampler {
     void rebuild();
     void init_state(uint32_t variant);
     void run(uint64_t updates, bool counting);
+    void burn_group(uint32_t group, uint32_t updates);
 };
 
 // Pick block size, LDS layout and conditional path for the current images.
@@ -366,7 +374,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     p.cprogs = d_cprogs.p; p.cprog_off = d_cprog_off.p; p.cpt = d_cpt.p;
     p.pprogs = d_pprogs.p; p.pprog_off = d_pprog_off.p;
     p.state = d_state.p; p.counts = d_counts.p;
-    p.n_vars = (uint32_t)n_vars; p.H = (uint32_t)H; p.n_chains = o.n_chains; p.pitch = pitch;
+    const uint32_t act = active_chains();
+    p.n_vars = (uint32_t)n_vars; p.H = (uint32_t)H; p.chain0 = 0; p.n_chains = act; p.pitch = pitch;
     p.chains_per_variant = cpv;
     p.chain_offset_lo = (uint32_t)o.chain_offset; p.chain_offset_hi = (uint32_t)(o.chain_offset >> 32);
     p.seed_lo = (uint32_t)o.seed; p.seed_hi = (uint32_t)(o.seed >> 32);
@@ -380,7 +389,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
             p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
             p.n_steps = n;
-            hip_check(launch_sweep(p, max_card, cpt, tab_lds, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, blocks, T, lds, stream), "k_sweep launch");
+            hip_check(launch_sweep(p, max_card, cpt, tab_lds, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, (act + T - 1) / T, T, lds, stream), "k_sweep launch");
             step += n;
             left -= n;
             launches_last++;
@@ -391,7 +400,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         if (T <= 256) { generic(n_total); return; }
         // blocks of 256 lanes: the layout offsets were sized for T lanes, which is larger -> still fits
         const uint32_t keepT = T, keepB = blocks;
-        T = 256; blocks = (o.n_chains + 255) / 256;
+        T = 256; blocks = (act + 255) / 256;
         generic(n_total);
         T = keepT; blocks = keepB;
     };
@@ -404,7 +413,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.cpt = d_cpt.p; f.recs = d_recs.p; f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p;
         f.plan_pitch = plan_steps;
         f.rec_stride = rec_stride;
-        f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = o.n_chains; f.pitch = pitch; f.chains_per_variant = cpv;
+        f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = act; f.pitch = pitch; f.chains_per_variant = cpv;
         f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
         f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi;
         f.counting = p.counting; f.lds_hist_off = lds_hist_off; f.lds_tab_off = lds_tab_off; f.lds_plan_off = lds_plan_off;
@@ -419,8 +428,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
             f.n_steps = n;
             hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
-            if (par) hip_check(launch_sweep_par4(f, fast_slots, par_packed, o.n_chains / 64u, par_lds, stream), "k_sweep_par4 launch");
-            else hip_check(launch_sweep_bin(f, fast_slots, blocks, T, lds, stream), "k_sweep_bin launch");
+            if (par) hip_check(launch_sweep_par4(f, fast_slots, par_packed, act / 64u, par_lds, stream), "k_sweep_par4 launch");
+            else hip_check(launch_sweep_bin(f, fast_slots, act / T, T, lds, stream), "k_sweep_bin launch");
             step += n;
             left -= n;
             launches_last++;
@@ -432,7 +441,35 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     float ms = 0;
     hip_check(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
     kernel_ms_last = ms;
-    if (counting) counted += updates;
+    if (counting) {
+        counted += updates;
+        for (uint32_t g = 0; g < (o.n_variants > 1 ? n_active : 1u); ++g) counted_g[g] += updates;
+    }
+}
+
+// A few uncounted updates on ONE group (NewChain's burn-in for a chain added by Adapt), through the
+// generic kernel restricted to that group's chains, at the step positions just before the current one.
+void gr_sampler::burn_group(uint32_t group, uint32_t updates) {
+    use();
+    if (dirty) rebuild();
+    SweepParams p{};
+    p.variants = d_variants.p;
+    p.progs = d_progs.p; p.prog_off = d_prog_off.p; p.views = d_views.p; p.free_vars = d_free.p;
+    p.cprogs = d_cprogs.p; p.cprog_off = d_cprog_off.p; p.cpt = d_cpt.p;
+    p.pprogs = d_pprogs.p; p.pprog_off = d_pprog_off.p;
+    p.state = d_state.p; p.counts = d_counts.p;
+    p.n_vars = (uint32_t)n_vars; p.H = (uint32_t)H; p.pitch = pitch; p.chains_per_variant = cpv;
+    p.chain0 = group * cpv; p.n_chains = (group + 1) * cpv;
+    p.chain_offset_lo = (uint32_t)o.chain_offset; p.chain_offset_hi = (uint32_t)(o.chain_offset >> 32);
+    p.seed_lo = (uint32_t)o.seed; p.seed_hi = (uint32_t)(o.seed >> 32);
+    const uint64_t s0 = step >= updates ? step - updates : 0;
+    p.step0_lo = (uint32_t)s0; p.step0_hi = (uint32_t)(s0 >> 32);
+    p.n_steps = updates; p.counting = 0; p.sequential = 0;
+    p.lds_hist_off = lds_hist_off; p.lds_tab_off = lds_tab_off;
+    const uint32_t t = std::min(T, 256u);
+    hip_check(launch_sweep(p, max_card, cpt, tab_lds, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, (cpv + t - 1) / t, t, lds, stream),
+              "k_sweep launch (group burn-in)");
+    sync();
 }
 
 // ============================================================== C ABI: general
@@ -621,6 +658,9 @@ GR_VISIBLE gr_sampler *gr_sampler_create(const gr_model *m, const gr_sampler_opt
         hip_check(hipEventCreate(&s->ev1), "hipEventCreate");
         Model base = m->m; // Model.Clone (root.go:385)
         base.Check();
+        s->base_linear = base;
+        s->n_active = opts->n_variants;
+        s->counted_g.assign(opts->n_variants, 0);
         s->n_vars = (int)base.Vars.size();
         s->H = base.TotalCard();
         for (auto &v : base.Vars) {
@@ -670,7 +710,7 @@ GR_VISIBLE int gr_collapse(gr_sampler *s, uint32_t variant, int32_t var_idx, int
     return guarded([&] {
         if (!s) throw Error(GR_E_INVALID, "null sampler");
         if (variant >= s->o.n_variants) throw Error(GR_E_INVALID, "variant out of range");
-        if (s->started) throw Error(GR_E_STATE, "gr_collapse must precede burn-in / advance");
+        if (s->started && variant < s->n_active) throw Error(GR_E_STATE, "gr_collapse must precede burn-in / advance (or target a group that is not active yet)");
         s->use();
         Model &pgm = s->vmodel[variant];
         const int N = s->n_vars;
@@ -791,7 +831,13 @@ GR_VISIBLE int gr_advance(gr_sampler *s, uint64_t updates_per_chain) {
 }
 GR_VISIBLE int gr_total_samples(gr_sampler *s, uint64_t *out) {
     if (!s || !out) return fail(GR_E_INVALID, "null argument");
-    *out = s->counted * (uint64_t)s->o.n_chains;
+    if (s->o.n_variants > 1) {
+        uint64_t t = 0;
+        for (uint32_t g = 0; g < s->n_active; ++g) t += s->counted_g[g] * (uint64_t)(s->o.n_chains / s->o.n_variants);
+        *out = t;
+    } else {
+        *out = s->counted * (uint64_t)s->o.n_chains;
+    }
     return GR_OK;
 }
 
@@ -803,7 +849,7 @@ GR_VISIBLE int gr_counts(gr_sampler *s, uint64_t *counts, uint64_t *n_updates) {
             hip_check(hipMemcpyAsync(counts, s->d_counts.p, (size_t)s->o.n_variants * s->H * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream), "D2H");
             s->sync();
         }
-        if (n_updates) *n_updates = s->counted * (uint64_t)s->o.n_chains;
+        if (n_updates && gr_total_samples(s, n_updates)) throw Error(GR_E_INVALID, g_err);
     });
 }
 GR_VISIBLE int gr_counts_device(gr_sampler *s, void **dptr, size_t *n_elems) {
@@ -833,7 +879,7 @@ GR_VISIBLE int gr_merge_local(gr_sampler *s, double *out_sum, int32_t *out_coll_
         for (int v = 0; v < s->n_vars; ++v) {
             out_coll_variant[v] = -1;
             const int C = s->card[v];
-            for (uint32_t g = 0; g < s->o.n_variants; ++g) {
+            for (uint32_t g = 0; g < (s->o.n_variants > 1 ? s->n_active : 1u); ++g) {
                 const Variable &var = s->vmodel[g].Vars[v];
                 if (var.Collapsed) {
                     if (out_coll_variant[v] < 0) {
@@ -912,6 +958,155 @@ GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t 
             if (r != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclAllReduce failed");
         }
         if (out && gr_counts(samplers[0], out, nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
+    });
+}
+
+
+// ============================================================ adaptive (N2)
+GR_VISIBLE int gr_set_active_groups(gr_sampler *s, uint32_t n_active) {
+    return guarded([&] {
+        if (!s) throw Error(GR_E_INVALID, "null sampler");
+        if (s->started) throw Error(GR_E_STATE, "gr_set_active_groups must precede burn-in / advance");
+        if (n_active < 1 || n_active > s->o.n_variants) throw Error(GR_E_INVALID, "n_active out of range");
+        s->n_active = n_active;
+    });
+}
+GR_VISIBLE int gr_active_groups(gr_sampler *s) { return s ? (int)s->n_active : fail(GR_E_INVALID, "null sampler"); }
+
+GR_VISIBLE int gr_advance_window(gr_sampler *s, uint64_t updates_per_chain) {
+    return guarded([&] {
+        if (!s) throw Error(GR_E_INVALID, "null sampler");
+        if (updates_per_chain < 2) throw Error(GR_E_INVALID, "a convergence window needs at least 2 updates");
+        const size_t n = (size_t)s->o.n_variants * s->H;
+        std::vector<uint64_t> c0(n), c1(n), c2(n);
+        if (gr_counts(s, c0.data(), nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
+        const uint64_t h1 = updates_per_chain / 2;
+        s->run(h1, true);
+        double ms = s->kernel_ms_last;
+        uint32_t nl = s->launches_last;
+        if (gr_counts(s, c1.data(), nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
+        s->run(updates_per_chain - h1, true);
+        s->kernel_ms_last += ms;
+        s->launches_last += nl;
+        if (gr_counts(s, c2.data(), nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
+        s->win_first.assign(n, 0.0);
+        s->win_second.assign(n, 0.0);
+        for (size_t i = 0; i < n; ++i) {
+            s->win_first[i] = (double)(c1[i] - c0[i]);
+            s->win_second[i] = (double)(c2[i] - c1[i]);
+        }
+        // ConvergenceWindow ~ samples of one variable in one chain of the window
+        s->win_cw = std::max(2.0, (double)updates_per_chain / (double)std::max<size_t>(1, s->image[0].free_vars.size()));
+    });
+}
+
+GR_VISIBLE int gr_chain_convergence(int32_t n_groups, int32_t n_vars, const int32_t *card, const int32_t *fixed,
+                                    const int32_t *merged_collapsed, const double *first, const double *second,
+                                    const double *merged, double cw, int32_t measure, double *out) {
+    return guarded([&] {
+        if (n_groups < 2) throw Error(GR_E_INVALID, "Convergence requires at least 2 chains");
+        if (n_vars < 1 || !card || !first || !second || !merged || !out) throw Error(GR_E_INVALID, "null argument");
+        int H = 0;
+        for (int v = 0; v < n_vars; ++v) H += card[v];
+        auto dist = [&](const double *a, const double *b, int c) -> double {
+            switch (measure) {
+            case 1: return JSDivergence(a, b, c);
+            case 2: return MaxAbsDiff(a, b, c);
+            case 3: return MeanAbsDiff(a, b, c);
+            default: return HellingerDiff(a, b, c);
+            }
+        };
+        const double m = (double)n_groups;
+        const double bNorm = cw / (m - 1.0), wFactor = (cw - 1.0) / cw, bFactor = (m + 1.0) / (m * cw); // chain.go:52-59
+        std::vector<double> v1, v2;
+        int off = 0;
+        for (int i = 0; i < n_vars; ++i) {
+            const int c = card[i];
+            if ((merged_collapsed && merged_collapsed[i]) || (fixed && fixed[i] >= 0)) { out[i] = 1.0; off += c; continue; }
+            double W = 1e-8, B = 1e-8;
+            for (int g = 0; g < n_groups; ++g) { // ChainDist (chain.go:253-290)
+                v1.assign(first + (size_t)g * H + off, first + (size_t)g * H + off + c);
+                v2.assign(second + (size_t)g * H + off, second + (size_t)g * H + off + c);
+                for (int k = 0; k < c; ++k) { v1[k] += 1e-8; v2[k] += 1e-8; }
+                W += dist(v1.data(), v2.data(), c);
+                for (int k = 0; k < c; ++k) v1[k] += v2[k];
+                B += dist(merged + off, v1.data(), c);
+            }
+            W /= m;
+            B *= bNorm;
+            const double vhat = wFactor * W + bFactor * B;
+            out[i] = std::sqrt((4.0 * vhat) / (2.0 * W));
+            off += c;
+        }
+    });
+}
+
+GR_VISIBLE int gr_adapt_select(const gr_model *base, const int32_t *merged_collapsed, const double *converge, uint32_t new_chain_count,
+                               int32_t *out_vars, uint32_t *out_n) {
+    return guarded([&] {
+        if (!base || !out_vars || !out_n) throw Error(GR_E_INVALID, "null argument");
+        *out_n = 0;
+        const Model &m = base->m;
+        const auto nbrs = VarNeighbors(m); // BlanketSize (gibbs-collapsed.go:81-83)
+        std::vector<int> vars;
+        for (size_t v = 0; v < m.Vars.size(); ++v) {
+            const int sz = (int)nbrs[v].size();
+            if (m.Vars[v].FixedVal < 0 && !(merged_collapsed && merged_collapsed[v]) && sz > 1 && sz <= kNeighborVarMax) vars.push_back((int)v);
+        }
+        if (vars.empty() || new_chain_count == 0) return;
+        if (vars.size() <= new_chain_count) {
+            for (int v : vars) out_vars[(*out_n)++] = v;
+            return;
+        }
+        if (!converge) throw Error(GR_E_INVALID, "more candidates than slots: convergence scores are required");
+        std::stable_sort(vars.begin(), vars.end(), [&](int a, int b) { return converge[a] > converge[b]; });
+        for (uint32_t cc = 0, pos = (uint32_t)vars.size() - 1; cc < new_chain_count; ++cc, --pos) out_vars[(*out_n)++] = vars[pos];
+    });
+}
+
+GR_VISIBLE int gr_adapt(gr_sampler *s, uint32_t new_chain_count, int32_t *out_vars, uint32_t *out_n, double *out_converge) {
+    return guarded([&] {
+        if (!s || !out_vars || !out_n) throw Error(GR_E_INVALID, "null argument");
+        *out_n = 0;
+        if (out_converge) std::fill(out_converge, out_converge + s->n_vars, std::nan(""));
+        if (s->o.n_variants < 2) throw Error(GR_E_INVALID, "adaptation needs a sampler with several chain groups");
+        if (s->n_active < 2) throw Error(GR_E_INVALID, "At least 2 chains required for adaptation");
+        if (s->n_active >= s->o.n_variants) return; // MaxChains reached (adaptive.go:62-64)
+        std::vector<double> sum(s->H), cm(s->H), merged(s->H);
+        std::vector<int32_t> cvv(s->n_vars), coll(s->n_vars);
+        if (gr_merge_local(s, sum.data(), cvv.data(), cm.data())) throw Error(GR_E_NO_DEVICE, g_err);
+        int off = 0;
+        for (int v = 0; v < s->n_vars; ++v) {
+            coll[v] = cvv[v] >= 0;
+            for (int k = 0; k < s->card[v]; ++k) merged[off + k] = coll[v] ? cm[off + k] : sum[off + k];
+            off += s->card[v];
+        }
+        gr_model base{s->base_linear};
+        const uint32_t slots = std::min<uint32_t>(new_chain_count, s->o.n_variants - s->n_active);
+        std::vector<double> conv;
+        uint32_t n_sel = 0;
+        std::vector<int32_t> sel(std::max<uint32_t>(slots, 1));
+        int rc = gr_adapt_select(&base, coll.data(), nullptr, slots, sel.data(), &n_sel);
+        if (rc) { // more candidates than slots: rank by ChainConvergence over the active groups
+            if (s->win_first.empty()) throw Error(GR_E_STATE, "gr_adapt needs a preceding gr_advance_window");
+            conv.resize(s->n_vars);
+            if (gr_chain_convergence((int32_t)s->n_active, s->n_vars, s->card.data(), s->fixed.data(), coll.data(), s->win_first.data(),
+                                     s->win_second.data(), merged.data(), s->win_cw, 0, conv.data()))
+                throw Error(GR_E_INVALID, g_err);
+            if (out_converge) std::copy(conv.begin(), conv.end(), out_converge);
+            if (gr_adapt_select(&base, coll.data(), conv.data(), slots, sel.data(), &n_sel)) throw Error(GR_E_INVALID, g_err);
+        }
+        for (uint32_t i = 0; i < n_sel; ++i) { // adaptive.go:131-153
+            const uint32_t g = s->n_active;
+            int32_t cv = -1;
+            if (gr_collapse(s, g, sel[i], &cv, nullptr)) throw Error(GR_E_COLLAPSE, g_err);
+            s->n_active = g + 1;
+            s->counted_g[g] = 0;
+            // NewChain(..., burnIn = 2): two uncounted updates on the new group only, at step positions it has not used
+            if (s->dirty) s->rebuild();
+            s->burn_group(g, 2);
+            out_vars[(*out_n)++] = cv;
+        }
     });
 }
 

@@ -194,6 +194,39 @@ typedef struct gr_sampler_info {
 } gr_sampler_info;
 int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out);
 
+/* ------------------------------------------------------- adaptive sampler (N2)
+ * ConvergenceSampler.Adapt (sampler/adaptive.go:57-157) + ChainConvergence (sampler/chain.go:32-92).
+ * A chain GROUP plays the role of one reference chain: same model clone, same collapsed variable.
+ * The sampler is created with n_variants = the most groups it may ever hold (reference MaxChains = 128,
+ * adaptive.go:49); only the first gr_active_groups() run, and gr_adapt activates more. */
+
+/* number of groups that sample / are merged; set before the first burn-in (default: all) */
+int gr_set_active_groups(gr_sampler *s, uint32_t n_active);
+int gr_active_groups(gr_sampler *s);
+/* AdvanceChain over a convergence window: like gr_advance, and additionally keeps, per group, the
+ * histograms of the first and of the second half of this window -- the two halves ChainDist
+ * (chain.go:253-290) reads from ChainHistory.  (The reference's ring holds each variable's last
+ * cw selections; here the halves are the two halves of the window in time.) */
+int gr_advance_window(gr_sampler *s, uint64_t updates_per_chain);
+/* ChainConvergence (chain.go:32-92) as a pure function: first/second [n_groups*total_card] half-window
+ * histograms (any non-negative numbers; 1e-8 is added like ChainDist does), merged [total_card],
+ * merged_collapsed [n_vars] (may be NULL), cw = ConvergenceWindow, measure 0 Hellinger / 1 JS /
+ * 2 MaxAbs / 3 MeanAbs.  out [n_vars]; collapsed or fixed variables score 1.0. */
+int gr_chain_convergence(int32_t n_groups, int32_t n_vars, const int32_t *card, const int32_t *fixed,
+                         const int32_t *merged_collapsed, const double *first, const double *second,
+                         const double *merged, double cw, int32_t measure, double *out);
+/* The selection rule of Adapt (adaptive.go:78-119): eligible = free, not collapsed in the merge,
+ * blanket size 2..12 on the base model; if there are no more candidates than slots all are taken in
+ * id order, else they are sorted by descending score and taken from the TAIL (lowest scores first).
+ * converge may be NULL when no ranking is needed.  out_vars [new_chain_count]. */
+int gr_adapt_select(const gr_model *base, const int32_t *merged_collapsed, const double *converge,
+                    uint32_t new_chain_count, int32_t *out_vars, uint32_t *out_n);
+/* Adapt: merge the active groups, rank with the halves kept by the last gr_advance_window, and for
+ * every selected variable activate one more group: Collapse(var) on a fresh clone of the base model,
+ * NewChain with a burn-in of 2 updates (adaptive.go:131-153).  Nothing happens once all n_variants
+ * groups are active.  out_converge [n_vars] may be NULL. */
+int gr_adapt(gr_sampler *s, uint32_t new_chain_count, int32_t *out_vars, uint32_t *out_n, double *out_converge);
+
 /* Philox4x32-10 block function on the host (same code the device runs);
  * exported so the known-answer vectors can be checked without a GPU. */
 void gr_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);

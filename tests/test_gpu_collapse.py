@@ -232,3 +232,55 @@ def test_collapsed_full_size_properties(res_dir):
     free_everywhere = [v for v in range(n) if v not in first]
     v0 = free_everywhere[0]
     assert merged[v0].sum() == pytest.approx(K * cpv + ca[:, off[v0]:off[v0 + 1]].sum(), rel=1e-12)
+
+
+def test_adaptive_flow(res_dir):
+    """N2: `--sampler adaptive` (cmd/root.go:408-415, 542-560; adaptive.go:57-157) on the device: start with
+    2 un-collapsed groups, after every convergence window Adapt activates up to 4 more groups, each with one
+    more collapsed variable, until all groups are in use; then Adapt is the identity."""
+    name = "Segmentation_11.uai"
+    pm = uai_py.load(res_dir, name)
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    n, K, cpv = len(pm.card), 12, 64
+    off = np.concatenate([[0], np.cumsum(pm.card)])
+
+    def flow(seed):
+        s = g.HIPChains.NewGibbsCollapsed(gm, K * cpv, K, seed=seed)
+        s.set_active_groups(2)
+        with pytest.raises(g.GrError):
+            s.Adapt(4)  # needs a convergence window first (more candidates than slots)
+        s.BurnIn(5 * n)
+        added, sizes = [], []
+        for rnd in range(5):
+            s.AdvanceWindow(8 * n)
+            new, conv = s.Adapt(4)
+            added += new
+            sizes.append(s.active_groups())
+            if new:
+                elig = ~np.isnan(conv)
+                assert elig.all()
+                # picked from the tail of the descending order: no eligible, un-collapsed variable scores lower
+                coll_before = set(added[:-len(new)])
+                cand = [v for v in range(n) if v not in coll_before and 1 < s.BlanketSize(0, v) <= 12]
+                lowest = sorted(cand, key=lambda v: (conv[v], -v))[:len(new)]
+                assert sorted(conv[new]) == pytest.approx(sorted(conv[lowest]))
+        return s, added, sizes
+
+    s, added, sizes = flow(21)
+    assert sizes == [6, 10, 12, 12, 12] and len(added) == 10 and len(set(added)) == 10
+    merged, coll = g.MergeChains([s])
+    assert sorted(np.where(coll)[0].tolist()) == sorted(added)
+    cnt = s.counts()
+    for k, v in enumerate(added):  # group 2+k collapsed `v`: never sampled there; groups 0,1 sample everything
+        assert cnt[2 + k, off[v]:off[v + 1]].sum() == 0
+    assert (cnt[0].reshape(-1) > 0).any() and int(cnt.sum()) == s.TotalSampleCount()
+    # groups joined late: fewer counted updates than the base groups, in activation order
+    per_group = cnt.sum(axis=1)
+    assert per_group[0] == per_group[1] == 5 * 8 * n * cpv
+    assert per_group[2] == per_group[5] == 4 * 8 * n * cpv and per_group[6] == 3 * 8 * n * cpv and per_group[10] == 2 * 8 * n * cpv
+    # deterministic for a seed, different for another
+    s2, added2, _ = flow(21)
+    assert added2 == added and np.array_equal(s2.counts(), cnt)
+    sol = uai_py.load_mar(res_dir, name)
+    es = g.NewErrorSuite(pm.card, sol, merged)
+    assert es["MeanHellinger"] < 0.35  # sanity: a usable estimate

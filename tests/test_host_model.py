@@ -227,3 +227,65 @@ def test_host_code_under_sanitizers(res_dir, tmp_path):
     out = subprocess.run([exe] + files, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "ERROR" not in out.stdout and out.stdout.count("image_words") == 2 * len(files)
+
+
+def _oracle_ensemble_halves(oracle, L, e, n_chains, nv, cw):
+    import ctypes as Cc
+
+    class Chain(Cc.Structure):
+        _fields_ = [("target", Cc.c_void_p), ("simple", Cc.c_void_p), ("coll", Cc.c_void_p), ("cw", Cc.c_int),
+                    ("history", Cc.POINTER(Cc.c_void_p))]
+    half = cw // 2
+    tmp = np.zeros(half, dtype=np.int32)
+    first = np.zeros((n_chains, 2 * nv)); second = np.zeros((n_chains, 2 * nv))
+    for c in range(n_chains):
+        ch = Cc.cast(L.orc_ensemble_chain(e, c), Cc.POINTER(Chain)).contents
+        for v in range(nv):
+            if L.orc_ring_half(ch.history[v], 0, tmp.ctypes.data_as(Cc.POINTER(Cc.c_int))) == half:
+                first[c, 2 * v:2 * v + 2] = np.bincount(tmp, minlength=2)
+            if L.orc_ring_half(ch.history[v], 1, tmp.ctypes.data_as(Cc.POINTER(Cc.c_int))) == half:
+                second[c, 2 * v:2 * v + 2] = np.bincount(tmp, minlength=2)
+    return first, second
+
+
+def test_chain_convergence_and_adapt_select_match_oracle(oracle, res_dir):
+    """N2 host logic: gr_chain_convergence == the oracle's ChainConvergence (chain.go:32-92) on the same
+    half-window histograms, for all four measures; gr_adapt_select == the oracle's Adapt picks
+    (adaptive.go:78-119) given the same scores, incl. the second round where collapsed variables drop out."""
+    L = oracle.lib()
+    pm = uai_py.load(res_dir, "Grids_11.uai")
+    obase = oracle.Model.from_parsed(pm)
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai"))
+    cw, nv = 40, 100
+    e = L.orc_ensemble_new(obase.ptr, 42, 3, cw, 500)
+    assert L.orc_ensemble_advance(e) == 0
+    merged = np.zeros(200); coll = np.zeros(nv, dtype=np.int32)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+    ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))
+    assert L.orc_ensemble_merge(e, dp(merged), ip(coll)) == 0
+    first, second = _oracle_ensemble_halves(oracle, L, e, 3, nv, cw)
+    for measure in range(4):
+        oc = np.zeros(nv)
+        assert L.orc_ensemble_convergence(e, measure, dp(oc)) == 0
+        gc = g.ChainConvergence(pm.card, pm.fixed, coll, first, second, merged, cw, measure)
+        assert np.allclose(gc, oc, rtol=1e-12), measure
+    with pytest.raises(g.GrError):
+        g.ChainConvergence(pm.card, pm.fixed, coll, first[:1], second[:1], merged, cw)  # needs >= 2 chains
+    picked_all = []
+    for rnd in range(2):
+        out_vars = np.zeros(8, dtype=np.int32); n_out = C.c_int(); conv = np.zeros(nv)
+        L.orc_ensemble_merge(e, dp(merged), ip(coll))
+        assert L.orc_ensemble_adapt(e, 4, ip(out_vars), C.byref(n_out), dp(conv)) == 0
+        assert g.AdaptSelect(gm, coll, conv, 4) == out_vars[:n_out.value].tolist()
+        picked_all += out_vars[:n_out.value].tolist()
+        assert L.orc_ensemble_advance(e) == 0
+    assert len(set(picked_all)) == 8
+    L.orc_ensemble_free(e)
+    # fewer candidates than slots: every eligible variable in id order, no scores needed
+    small = g.Model.NewModelFromFile(os.path.join(res_dir, "sample.uai"))
+    assert g.AdaptSelect(small, [0, 0, 0], None, 5) == [0, 1, 2]
+    assert g.AdaptSelect(small, [0, 1, 0], None, 5) == [0, 2]
+    with pytest.raises(g.GrError):
+        g.AdaptSelect(gm, np.zeros(nv, dtype=np.int32), None, 4)  # ranking needed but no scores
+    one = g.Model.NewModelFromFile(os.path.join(res_dir, "one.uai"))
+    assert g.AdaptSelect(one, [0], None, 3) == []  # blanket of size 1 is never eligible (adaptive.go:84)

@@ -6,7 +6,7 @@
 // the HIP library; this file contains no sampling code.  The reference's Go CLI stays the real
 // front end; this is the compiled-language host the image can build (no Go here).
 //
-//   grample_hip_sample -m MODEL.uai [-s simple|collapsed] [-o] [-d] [-c CHAINS] [-k GROUPS]
+//   grample_hip_sample -m MODEL.uai [-s simple|collapsed|adaptive] [-o] [-d] [-c CHAINS] [-k GROUPS]
 //                      [-b BURNIN] [-i MAXITERS] [-r ROUNDS] [-e SEED] [--device N]
 #include <chrono>
 #include <cmath>
@@ -45,8 +45,8 @@ int main(int argc, char **argv) {
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
     }
     if (model.empty()) { std::fprintf(stderr, "usage: %s -m MODEL.uai [-s simple|collapsed] [-o] [-d] [-c chains] ...\n", argv[0]); return 2; }
-    const bool collapsed = samp == "collapsed";
-    if (!collapsed && samp != "simple") { std::fprintf(stderr, "Unknown Sampler: %s\n", samp.c_str()); return 2; }
+    const bool collapsed = samp == "collapsed", adaptive = samp == "adaptive";
+    if (!collapsed && !adaptive && samp != "simple") { std::fprintf(stderr, "Unknown Sampler: %s\n", samp.c_str()); return 2; }
 
     std::printf("Reading model from %s\n", model.c_str());
     gr_model *m = gr_model_from_file(model.c_str(), use_evidence ? 1 : 0);
@@ -68,7 +68,7 @@ int main(int argc, char **argv) {
     // defaults as in cmd/root.go:348-356
     if (burnin < 0) burnin = 2000L * n;
     if (maxiters < 0) maxiters = 20000L * n;
-    if (groups <= 0) groups = collapsed ? 128 : 1; // reference MaxChains (adaptive.go:49)
+    if (groups <= 0) groups = (collapsed || adaptive) ? 128 : 1; // reference MaxChains (adaptive.go:49)
     if (chains % groups) chains -= chains % groups;
 
     gr_sampler_opts o{};
@@ -87,6 +87,7 @@ int main(int argc, char **argv) {
             if (gr_collapse(s, (uint32_t)k, -1, &cv, marg.data())) die("Could not collapse random var on startup");
             if (k < 4) std::printf("        - group %ld collapsed variable %d\n", k, cv);
         }
+    if (adaptive && gr_set_active_groups(s, 2)) die("Could not set the base chain count"); // root.go:360-363: at least 2 base chains
     if (gr_burnin(s, (uint64_t)burnin)) die("Failure during chain burn in");
 
     std::printf("Main Sampling Start\n");
@@ -96,7 +97,7 @@ int main(int argc, char **argv) {
     const uint64_t per_round = (uint64_t)std::max(1L, maxiters / std::max(1L, rounds));
     double es[8];
     for (long r = 0; r < rounds; ++r) {
-        if (gr_advance(s, per_round)) die("Async sample generation failed");
+        if (adaptive ? gr_advance_window(s, per_round) : gr_advance(s, per_round)) die("Async sample generation failed");
         uint64_t samples = 0;
         gr_total_samples(s, &samples);
         gr_sampler *one[1] = {s};
@@ -108,6 +109,13 @@ int main(int argc, char **argv) {
             std::printf(" | MeanHellinger %.6f MaxHellinger %.6f MeanMAE %.6f", es[2], es[6], es[0]);
         }
         std::printf("\n");
+        if (adaptive && r < rounds / 2) { // adaptation only during the first half of the run (root.go:469,542-547)
+            std::vector<int32_t> nv(4);
+            uint32_t nn = 0;
+            const int pre = gr_active_groups(s);
+            if (gr_adapt(s, 4, nv.data(), &nn, nullptr)) die("Adapt failed");
+            if (nn) std::printf("ADAPT: %d Chain groups (was %d)\n", gr_active_groups(s), pre);
+        }
     }
     std::printf("DONE\n");
     if (use_solution) std::printf("FINAL MeanHellinger=%.8f MaxHellinger=%.8f MeanJS=%.8f MaxJS=%.8f\n", es[2], es[6], es[3], es[7]);
