@@ -399,10 +399,12 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     auto generic_small = [&](uint64_t n_total) {
         if (T <= 256) { generic(n_total); return; }
         // blocks of 256 lanes: the layout offsets were sized for T lanes, which is larger -> still fits
-        const uint32_t keepT = T, keepB = blocks;
+        struct Restore { // the geometry is restored even when a launch throws
+            uint32_t &t, &b, kt, kb;
+            ~Restore() { t = kt; b = kb; }
+        } restore{T, blocks, T, blocks};
         T = 256; blocks = (act + 255) / 256;
         generic(n_total);
-        T = keepT; blocks = keepB;
     };
     if (!fast) {
         generic(updates);
