@@ -206,20 +206,23 @@ def _group_props(counts, cards):
     return p
 
 
-@pytest.mark.parametrize("name,burn_sw,upd_sw,per", [("Grids_11.uai", 10, 30, 16), ("Segmentation_11.uai", 10, 30, 8),
-                                                     ("ObjectDetection_13.uai", 10, 40, 8)])
-def test_marginals_match_oracle_runs(oracle, res_dir, name, burn_sw, upd_sw, per):
+@pytest.mark.parametrize("name,burn_sw,upd_sw,per,ev", [("Grids_11.uai", 10, 30, 16, False), ("Segmentation_11.uai", 10, 30, 8, False),
+                                                        ("ObjectDetection_13.uai", 10, 40, 8, False),
+                                                        ("Pedigree_11.uai", 5, 15, 4, True),   # evidence, Card 3, arity 4
+                                                        ("CSP_12.uai", 10, 30, 8, False),      # Card 4, arity 3
+                                                        ("Promedus_11.uai", 5, 15, 4, True)])  # evidence, binary, arity 3
+def test_marginals_match_oracle_runs(oracle, res_dir, name, burn_sw, upd_sw, per, ev):
     """Two-sample test, oracle (MT19937-64, f64, Go semantics) vs GPU (Philox, f32 tables): same
     burn-in and update counts per chain.  Both sides are run as G independent groups; a group's
     histogram shares are i.i.d. across groups, so for every (variable, value)
         z = (mean_oracle - mean_gpu) / sqrt(se_oracle^2 + se_gpu^2)
     is ~N(0,1) if and only if the two samplers have the same law at that horizon (mixed or not).
     Stated tolerance: max |z| <= 5.5 and mean z^2 <= 2 over all (variable, value) pairs."""
-    pm = uai_py.load(res_dir, name)
+    pm = uai_py.load(res_dir, name, ev)
     n = len(pm.card)
     burn, upd = burn_sw * n, upd_sw * n
     G = 32
-    s = g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, name)), G * 64, n_variants=G, seed=42)
+    s = g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, name), ev), G * 64, n_variants=G, seed=42)
     s.BurnIn(burn); s.Advance(upd)
     pg = _group_props(s.counts(), pm.card)
     om = oracle.Model.from_parsed(pm)
@@ -233,13 +236,16 @@ def test_marginals_match_oracle_runs(oracle, res_dir, name, burn_sw, upd_sw, per
     po = _group_props(np.rint(co), pm.card)
     se = np.sqrt(po.var(axis=0, ddof=1) / G + pg.var(axis=0, ddof=1) / G)
     z = (po.mean(axis=0) - pg.mean(axis=0)) / np.maximum(se, 2e-4)
+    free = np.concatenate([np.full(c, f < 0) for c, f in zip(pm.card, pm.fixed)])
+    assert np.all(pg[:, ~free] == 0) and np.all(po[:, ~free] == 0)  # evidence variables are never sampled on either side
+    z = z[free]
     assert np.max(np.abs(z)) <= 5.5, (name, np.max(np.abs(z)), np.argmax(np.abs(z)))
     assert np.mean(z ** 2) <= 2.0, (name, np.mean(z ** 2))
     # and the headline metric agrees: Hellinger vs res/<model>.uai.MAR is the same for both
     sol = uai_py.load_mar(res_dir, name)
     split = lambda flat: g.split(flat, pm.card)
-    eo = g.NewErrorSuite(pm.card, sol, split(po.mean(axis=0) + 1e-12))
-    eg = g.NewErrorSuite(pm.card, sol, split(pg.mean(axis=0) + 1e-12))
+    eo = g.NewErrorSuite(pm.card, sol, split(po.mean(axis=0) + 1e-12), fixed1=pm.fixed)
+    eg = g.NewErrorSuite(pm.card, sol, split(pg.mean(axis=0) + 1e-12), fixed1=pm.fixed)
     assert abs(eo["MeanHellinger"] - eg["MeanHellinger"]) <= 0.02, (eo, eg)
 
 
