@@ -284,3 +284,29 @@ def test_adaptive_flow(res_dir):
     sol = uai_py.load_mar(res_dir, name)
     es = g.NewErrorSuite(pm.card, sol, merged)
     assert es["MeanHellinger"] < 0.35  # sanity: a usable estimate
+
+
+def test_many_chains_grouped_chain_per_lane_fast_path(res_dir):
+    """The chain-per-lane fast kernel (used from 98 304 chains up) with several collapsed groups: bit-identical
+    to the direct path, and to the 4-lanes-per-chain form forced on the same problem."""
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai"))
+    n, K, cpv = 100, 8, 16384
+
+    def run(flags=0, form=0):
+        s = g.HIPChains(gm, K * cpv, n_variants=K, seed=3, flags=flags, fast_form=form)
+        cvs = [s.Collapse(k, -1)[0] for k in range(K)]
+        s.BurnIn(2 * n + 1)
+        s.Advance(3 * n + 5)
+        return s, cvs
+
+    a, cva = run()
+    assert a.info()["path"] == 2
+    b, cvb = run(form=2)
+    assert b.info()["path"] == 3 and cvb == cva
+    d, cvd = run(g.GR_FLAG_DIRECT)
+    assert d.info()["path"] == 0 and cvd == cva
+    ca = a.counts()
+    assert int(ca.sum()) == K * cpv * (3 * n + 5)
+    assert np.array_equal(ca, b.counts()) and np.array_equal(ca, d.counts())
+    for c in (0, cpv + 7, K * cpv - 1):
+        assert np.array_equal(a.LastSample(c), d.LastSample(c)) and np.array_equal(a.LastSample(c), b.LastSample(c))
