@@ -51,7 +51,10 @@ COND_ABS, COND_REL = 4e-10, 5e-5
 @pytest.mark.parametrize("name,ev", [("one.uai", False), ("sample.uai", False), ("deterministic.uai", False),
                                      ("Grids_11.uai", False), ("Grids_13.uai", False), ("Segmentation_11.uai", False),
                                      ("ObjectDetection_13.uai", False), ("Promedus_11.uai", True),
-                                     ("Pedigree_11.uai", True), ("CSP_12.uai", False)])
+                                     ("Pedigree_11.uai", True), ("CSP_12.uai", False),
+                                     ("ObjectDetection_11.uai", False),  # Card 11 < the kernel's 16-wide rows
+                                     ("Alchemy_11.uai", False),          # blankets up to 60 variables, arity 3
+                                     ("dv-rel_2.uai", True)])            # 1200 variables, arity 4, 307 evidence variables
 def test_conditional_matches_oracle(oracle, res_dir, name, ev):
     """a4-a8: gather + log-sum + stabilise/exp/floor + normalise (gibbs-simple.go:175-258)."""
     pm = uai_py.load(res_dir, name, ev)
@@ -210,7 +213,9 @@ def _group_props(counts, cards):
                                                         ("ObjectDetection_13.uai", 10, 40, 8, False),
                                                         ("Pedigree_11.uai", 5, 15, 4, True),   # evidence, Card 3, arity 4
                                                         ("CSP_12.uai", 10, 30, 8, False),      # Card 4, arity 3
-                                                        ("Promedus_11.uai", 5, 15, 4, True)])  # evidence, binary, arity 3
+                                                        ("Promedus_11.uai", 5, 15, 4, True),   # evidence, binary, arity 3
+                                                        ("ObjectDetection_11.uai", 10, 30, 8, False),  # Card 11
+                                                        ("Alchemy_11.uai", 5, 10, 4, False)])  # blankets up to 60
 def test_marginals_match_oracle_runs(oracle, res_dir, name, burn_sw, upd_sw, per, ev):
     """Two-sample test, oracle (MT19937-64, f64, Go semantics) vs GPU (Philox, f32 tables): same
     burn-in and update counts per chain.  Both sides are run as G independent groups; a group's

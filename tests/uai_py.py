@@ -114,7 +114,9 @@ def read_mar(text):
     for _ in range(nv):
         c = int(t[p]); p += 1
         m = np.array([float(x) for x in t[p:p + c]], dtype=np.float64); p += c
-        s = m.sum()  # NormMarginal (variable.go:106-147)
+        s = 0.0  # NormMarginal (variable.go:106-147): sequential sum like the Go loop (a pairwise sum can flip the 1e-8 test)
+        for x in m:
+            s += float(x)
         if abs(s - 1.0) >= 1e-8:
             m = np.full(c, 1.0 / c) if abs(s) < 1e-8 else m / s
         out.append(m)
