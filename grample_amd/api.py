@@ -251,6 +251,18 @@ class HIPChains:
     def AdvanceWindow(self, updates_per_chain):
         _chk(self.L.gr_advance_window(self.ptr, updates_per_chain))
 
+    def AdvanceChain(self, cw):
+        """Chain.AdvanceChain with the reference's stopping rule; returns the updates run per chain."""
+        n = C.c_uint64()
+        _chk(self.L.gr_advance_chain(self.ptr, cw, C.byref(n)))
+        return n.value
+
+    def window_halves(self):
+        a = np.zeros((self.n_variants, self.H)); b = np.zeros((self.n_variants, self.H))
+        cw = C.c_double()
+        _chk(self.L.gr_window_halves(self.ptr, _p(a, C.c_double), _p(b, C.c_double), C.byref(cw)))
+        return a, b, cw.value
+
     def Adapt(self, newChainCount):
         """ConvergenceSampler.Adapt: returns (collapsed variables of the groups added, convergence scores or NaNs)."""
         out = np.zeros(max(newChainCount, 1), dtype=np.int32)

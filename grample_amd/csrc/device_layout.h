@@ -47,6 +47,11 @@ struct SweepParams {
     uint32_t sequential;        // 1 = never co-issue commuting updates
     uint32_t lds_hist_off;      // byte offsets inside dynamic LDS
     uint32_t lds_tab_off;
+    // optional draw log (ChainHistory rebuild): log[(chain >> 6) * log_pitch + log_off + step - step0] = number of
+    // chains of the wavefront whose binary update drew 1; null = off
+    unsigned char *log;
+    uint32_t log_pitch, log_off;
+    uint32_t log_rows;          // rows per 64-chain group in the log (4 when the 4-lane form writes it); this kernel uses the first
 };
 
 // Fast binary/memoised path (sweep_bin.hip).  A RECORD is one 64-byte line per
@@ -79,8 +84,23 @@ struct FastParams {
     uint32_t lds_hist_off, lds_tab_off;
     uint32_t lds_plan_off;       // per-wave plan ring: 2 x 64 quads x 16 B
     // step-parallel form (k_sweep_par4): its own records (80-byte state rows) and LDS layout
+    unsigned char *log;          // optional draw log, see SweepParams (4-lane form: one row per wavefront = 16 chains)
+    uint32_t log_pitch, log_off;
     const uint32_t *recs_par;
     uint32_t par_hist_off, par_tab_off, par_rec_off, par_plan_off, par_scr_off;
+};
+
+// Arguments of the scan-stream kernels behind gr_advance_chain (k_stop_time, k_ring_halves): one thread per
+// 64-chain scan group replays its variable-selection stream.
+struct ScanArgs {
+    const VariantDesc *variants;
+    const uint32_t *free_vars;
+    uint32_t n_groups;           // active chains / 64
+    uint32_t chains_per_variant;
+    uint32_t chain_offset_lo, chain_offset_hi;
+    uint32_t seed_lo, seed_hi;
+    uint32_t n_vars;
+    uint32_t step0_lo, step0_hi; // first step of the window
 };
 
 } // namespace gr

@@ -278,7 +278,8 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     };
 
     // g.last[v] = val (gibbs-simple.go:267) and Marginal[val] += 1 (chain.go:230-236)
-    auto commit = [&](const uint32_t v, const uint32_t *pg, const uint32_t val) {
+    unsigned char *logrow = p.log ? p.log + (size_t)(chain >> 6) * p.log_rows * p.log_pitch + p.log_off : nullptr;
+    auto commit = [&](const uint32_t v, const uint32_t *pg, const uint32_t val, const uint32_t sidx) {
         st[v * T] = (unsigned char)val;
         if (counting) {
             const uint32_t C = pg[0] & 0xffu, ho = pg[1];
@@ -287,6 +288,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
                 if (lane == 0) {
                     hist[ho] += nact - ones;
                     hist[ho + 1] += ones;
+                    if (logrow) logrow[sidx] = (unsigned char)ones;
                 }
             } else if (active) {
                 atomicAdd(&hist[ho + val], 1u);
@@ -338,7 +340,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
                     bool c = false;
                     nv[j] = sample(pg[j], du[j], 0xffffffffu, 0xffffffffu, 0xffffffffu, c);
                 }
-                commit(v[j], pg[j], nv[j]);
+                commit(v[j], pg[j], nv[j], (uint32_t)(((q << 2) + j) - step0));
             }
     }
 
@@ -480,6 +482,81 @@ __global__ void __launch_bounds__(256) k_collapse(const CollapseArgs a) {
     }
 }
 
+// ------------------------------------------------------------ scan-stream kernels
+// The variable a 64-chain group updates at step s (same arithmetic as k_sweep / k_scan_plan).
+struct ScanReplay {
+    const ScanArgs &a;
+    const uint32_t *freev;
+    uint32_t n_free, gid;
+    uint64_t cached_q = ~0ull;
+    u32x4 w{};
+    __device__ ScanReplay(const ScanArgs &args, uint32_t group) : a(args) {
+        const VariantDesc vd = a.variants[(group * 64u) / a.chains_per_variant];
+        freev = a.free_vars + vd.free_base;
+        n_free = vd.n_free;
+        const uint64_t gchain0 = (((uint64_t)a.chain_offset_hi << 32) | a.chain_offset_lo) + (uint64_t)group * 64u;
+        gid = (uint32_t)(gchain0 >> 6);
+    }
+    __device__ uint32_t var_at(uint64_t s) {
+        const uint64_t q = s >> 2;
+        if (q != cached_q) {
+            w = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), gid, DOM_SCAN, a.seed_lo, a.seed_hi);
+            cached_q = q;
+        }
+        const uint32_t j = (uint32_t)(s & 3u);
+        const uint32_t r = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
+        return freev[mul_hi_u32(r, n_free)];
+    }
+};
+
+// AdvanceChain's stopping rule (chain.go:184-215): batches of `batch` (= 2 N) updates until every selectable
+// variable of the group has been selected cw + 1 more times.  out[group] = number of batches.
+__global__ void k_stop_time(const ScanArgs a, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *counts /*[n_groups][n_vars]*/,
+                            uint32_t *out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_groups) return;
+    ScanReplay sr(a, g);
+    uint32_t *cnt = counts + (size_t)g * a.n_vars;
+    for (uint32_t i = 0; i < sr.n_free; ++i) cnt[sr.freev[i]] = 0;
+    uint32_t remaining = sr.n_free, b = 0;
+    uint64_t s = ((uint64_t)a.step0_hi << 32) | a.step0_lo;
+    while (b < max_batches && remaining) {
+        for (uint32_t i = 0; i < batch; ++i, ++s) {
+            const uint32_t v = sr.var_at(s);
+            if (++cnt[v] == cw + 1u) remaining--;
+        }
+        b++;
+    }
+    out[g] = remaining ? 0xffffffffu : b;
+}
+
+// ChainHistory's two halves (buffer/circular.go:54-84, chain.go:270-277), rebuilt from the draw log: walking the
+// window backwards, the newest `half` selections of a variable are its second half, the `half` before them its
+// first half.  ones[g][h][v] = number of chains that drew 1 in half h; status[g] = variables whose ring is not full.
+__global__ void k_ring_halves(const ScanArgs a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
+                              uint32_t *seen /*[n_groups][n_vars]*/, uint32_t *ones /*[n_groups][2][n_vars]*/, uint32_t *status) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.n_groups) return;
+    ScanReplay sr(a, g);
+    uint32_t *sn = seen + (size_t)g * a.n_vars;
+    uint32_t *o1 = ones + (size_t)g * 2u * a.n_vars; // first half
+    uint32_t *o2 = o1 + a.n_vars;                     // second half
+    for (uint32_t i = 0; i < sr.n_free; ++i) { const uint32_t v = sr.freev[i]; sn[v] = 0; o1[v] = 0; o2[v] = 0; }
+    const uint64_t step0 = ((uint64_t)a.step0_hi << 32) | a.step0_lo;
+    uint32_t remaining = sr.n_free;
+    for (uint32_t k = n_steps; k-- > 0 && remaining;) {
+        const uint32_t v = sr.var_at(step0 + k);
+        const uint32_t c = sn[v];
+        if (c >= 2u * half) continue;
+        uint32_t n1 = 0;
+        for (uint32_t r = 0; r < log_rows; ++r) n1 += log[((size_t)g * log_rows + r) * log_pitch + k];
+        if (c < half) o2[v] += n1; else o1[v] += n1;
+        sn[v] = c + 1u;
+        if (c + 1u == 2u * half) remaining--;
+    }
+    status[g] = remaining;
+}
+
 // ------------------------------------------------------------ host launchers
 #define GR_DISPATCH_MAXC(maxc, ...)                       \
     do {                                                    \
@@ -541,6 +618,17 @@ hipError_t launch_conditional(const VariantDesc &vd, const uint32_t *progs, cons
     GR_DISPATCH_MAXC(max_card, {
         hipLaunchKernelGGL((k_conditional<MC>), dim3(1), dim3(1), 0, s, vd, progs, prog_off, views, v, state, probs);
     });
+    return hipGetLastError();
+}
+
+hipError_t launch_stop_time(const ScanArgs &a, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *counts, uint32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_stop_time, dim3((a.n_groups + 63) / 64), dim3(64), 0, s, a, cw, batch, max_batches, counts, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
+                              uint32_t *seen, uint32_t *ones, uint32_t *status, hipStream_t s) {
+    hipLaunchKernelGGL(k_ring_halves, dim3((a.n_groups + 63) / 64), dim3(64), 0, s, a, n_steps, half, log, log_pitch, log_rows, seen, ones, status);
     return hipGetLastError();
 }
 

@@ -122,6 +122,10 @@ struct gr_sampler {
     std::vector<double> win_first, win_second;   // [n_variants * H] halves of the last convergence window
     double win_cw = 0;
     Model base_linear;                           // the caller's model as given (linear tables): Adapt clones it
+    // draw log of the current gr_advance_chain window (null = off)
+    unsigned char *cur_log = nullptr;
+    uint32_t cur_log_pitch = 0, cur_log_rows = 1;
+    uint64_t cur_log_step0 = 0;
     uint32_t active_chains() const { return o.n_variants > 1 ? n_active * (o.n_chains / o.n_variants) : o.n_chains; }
     double kernel_ms_last = 0;
     uint32_t launches_last = 0;
@@ -389,6 +393,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
             p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
             p.n_steps = n;
+            p.log = cur_log; p.log_pitch = cur_log_pitch; p.log_rows = cur_log_rows; p.log_off = (uint32_t)(step - cur_log_step0);
             hip_check(launch_sweep(p, max_card, cpt, tab_lds, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, (act + T - 1) / T, T, lds, stream), "k_sweep launch");
             step += n;
             left -= n;
@@ -429,6 +434,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             const uint32_t n = (uint32_t)std::min<uint64_t>(left - left % gran, plan_steps);
             f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
             f.n_steps = n;
+            f.log = cur_log; f.log_pitch = cur_log_pitch; f.log_off = (uint32_t)(step - cur_log_step0);
             hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
             if (par) hip_check(launch_sweep_par4(f, fast_slots, par_packed, act / 64u, par_lds, stream), "k_sweep_par4 launch");
             else hip_check(launch_sweep_bin(f, fast_slots, act / T, T, lds, stream), "k_sweep_bin launch");
@@ -999,6 +1005,114 @@ GR_VISIBLE int gr_advance_window(gr_sampler *s, uint64_t updates_per_chain) {
         }
         // ConvergenceWindow ~ samples of one variable in one chain of the window
         s->win_cw = std::max(2.0, (double)updates_per_chain / (double)std::max<size_t>(1, s->image[0].free_vars.size()));
+    });
+}
+
+
+GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_updates) {
+    return guarded([&] {
+        if (!s) throw Error(GR_E_INVALID, "null sampler");
+        if (cw < 2) throw Error(GR_E_INVALID, "ConvergenceWindow must be >= 2");
+        if (s->o.flags & GR_FLAG_SCAN_PER_CHAIN) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain is not available in strict per-chain scan mode");
+        s->use();
+        if (s->dirty) s->rebuild();
+        const uint32_t act = s->active_chains();
+        if (act % 64u) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain needs a multiple of 64 chains");
+        const uint32_t n_groups = act / 64u;
+        ScanArgs a{};
+        a.variants = s->d_variants.p; a.free_vars = s->d_free.p; a.n_groups = n_groups; a.chains_per_variant = s->cpv;
+        a.chain_offset_lo = (uint32_t)s->o.chain_offset; a.chain_offset_hi = (uint32_t)(s->o.chain_offset >> 32);
+        a.seed_lo = (uint32_t)s->o.seed; a.seed_hi = (uint32_t)(s->o.seed >> 32);
+        a.n_vars = (uint32_t)s->n_vars;
+        a.step0_lo = (uint32_t)s->step; a.step0_hi = (uint32_t)(s->step >> 32);
+        // 1. how long: batches of 2N updates until every variable of every group has cw + 1 new samples (chain.go:184-215)
+        const uint32_t batch = 2u * (uint32_t)s->n_vars;
+        const uint32_t max_batches = (uint32_t)std::min<uint64_t>((1ull << 31) / batch, 1u << 20);
+        DevBuf<uint32_t> d_cnt, d_out;
+        d_cnt.alloc((size_t)n_groups * s->n_vars);
+        d_out.alloc(n_groups);
+        hip_check(launch_stop_time(a, cw, batch, max_batches, d_cnt.p, d_out.p, s->stream), "k_stop_time");
+        std::vector<uint32_t> nb(n_groups);
+        hip_check(hipMemcpyAsync(nb.data(), d_out.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
+        s->sync();
+        uint32_t worst = 0;
+        for (uint32_t b : nb) {
+            if (b == 0xffffffffu) throw Error(GR_E_UNSUPPORTED, "ConvergenceWindow too large: a chain group would need more than 2^31 updates");
+            worst = std::max(worst, b);
+        }
+        const uint64_t L = (uint64_t)worst * batch; // every group runs as long as the slowest one
+        // 2. run, logging every step's ones-count when all selectable variables are binary
+        bool binary = true;
+        for (uint32_t g = 0; g < (s->o.n_variants > 1 ? s->n_active : 1u) && binary; ++g)
+            for (uint32_t v : s->image[g].free_vars) binary = binary && s->card[v] == 2;
+        const uint32_t rows = s->par ? 4u : 1u;
+        const uint64_t pitch = (L + 15u) & ~15ull;
+        const bool logging = binary && L <= 0xfffffff0ull && (uint64_t)n_groups * rows * pitch <= (16ull << 30);
+        const size_t nH = (size_t)s->o.n_variants * s->H;
+        DevBuf<unsigned char> d_log;
+        std::vector<uint64_t> c0(nH), c1(nH), c2(nH);
+        if (logging) {
+            d_log.alloc((size_t)n_groups * rows * pitch);
+            hip_check(hipMemsetAsync(d_log.p, 0, (size_t)n_groups * rows * pitch, s->stream), "hipMemset");
+            s->cur_log = d_log.p; s->cur_log_pitch = (uint32_t)pitch; s->cur_log_rows = rows; s->cur_log_step0 = s->step;
+        }
+        struct Off { gr_sampler *s; ~Off() { s->cur_log = nullptr; s->cur_log_rows = 1; } } off{s};
+        if (logging) {
+            s->run(L, true);
+        } else { // no exact rings: fall back to the two halves of the window in time (gr_advance_window)
+            if (gr_counts(s, c0.data(), nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
+            s->run(L / 2, true);
+            const double ms = s->kernel_ms_last; const uint32_t nl = s->launches_last;
+            if (gr_counts(s, c1.data(), nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
+            s->run(L - L / 2, true);
+            s->kernel_ms_last += ms; s->launches_last += nl;
+            if (gr_counts(s, c2.data(), nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
+        }
+        s->win_first.assign(nH, 0.0);
+        s->win_second.assign(nH, 0.0);
+        s->win_cw = (double)cw;
+        if (logging) {
+            // 3. rebuild every ring's halves: the last 2 * (cw / 2) selections of each variable (circular.go:16-28)
+            const uint32_t half = cw / 2u;
+            DevBuf<uint32_t> d_seen, d_ones, d_status;
+            d_seen.alloc((size_t)n_groups * s->n_vars);
+            d_ones.alloc((size_t)n_groups * 2u * s->n_vars);
+            d_status.alloc(n_groups);
+            hip_check(launch_ring_halves(a, (uint32_t)L, half, d_log.p, (uint32_t)pitch, rows, d_seen.p, d_ones.p, d_status.p, s->stream), "k_ring_halves");
+            std::vector<uint32_t> ones((size_t)n_groups * 2u * s->n_vars), status(n_groups);
+            hip_check(hipMemcpyAsync(ones.data(), d_ones.p, ones.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
+            hip_check(hipMemcpyAsync(status.data(), d_status.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
+            s->sync();
+            for (uint32_t st : status)
+                if (st) throw Error(GR_E_STATE, "a ChainHistory ring is not full after AdvanceChain (internal error)");
+            std::vector<uint32_t> hoff(s->n_vars, 0);
+            for (int v = 1; v < s->n_vars; ++v) hoff[v] = hoff[v - 1] + (uint32_t)s->card[v - 1];
+            for (uint32_t g = 0; g < n_groups; ++g) {
+                const uint32_t variant = (g * 64u) / s->cpv;
+                for (uint32_t v : s->image[variant].free_vars) {
+                    const double n1 = ones[((size_t)g * 2u + 0u) * s->n_vars + v], n2 = ones[((size_t)g * 2u + 1u) * s->n_vars + v];
+                    const size_t o = (size_t)variant * s->H + hoff[v];
+                    s->win_first[o + 1] += n1;  s->win_first[o] += 64.0 * half - n1;
+                    s->win_second[o + 1] += n2; s->win_second[o] += 64.0 * half - n2;
+                }
+            }
+        } else {
+            for (size_t i = 0; i < nH; ++i) {
+                s->win_first[i] = (double)(c1[i] - c0[i]);
+                s->win_second[i] = (double)(c2[i] - c1[i]);
+            }
+        }
+        if (out_updates) *out_updates = L;
+    });
+}
+
+GR_VISIBLE int gr_window_halves(gr_sampler *s, double *first, double *second, double *cw) {
+    return guarded([&] {
+        if (!s || !first || !second) throw Error(GR_E_INVALID, "null argument");
+        if (s->win_first.empty()) throw Error(GR_E_STATE, "no convergence window yet (gr_advance_window / gr_advance_chain)");
+        std::copy(s->win_first.begin(), s->win_first.end(), first);
+        std::copy(s->win_second.begin(), s->win_second.end(), second);
+        if (cw) *cw = s->win_cw;
     });
 }
 

@@ -192,13 +192,15 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
     }
     uint4 PV = ring_read(1); // plan of the NEXT quad, as uniform VGPRs
 
-    auto commit = [&](const Rec &r, const uint32_t val) {
+    unsigned char *logrow = p.log ? p.log + (size_t)wave_local * p.log_pitch + p.log_off : nullptr;
+    auto commit = [&](const Rec &r, const uint32_t val, const uint32_t sidx) {
         st[r.w[0]] = (unsigned char)val;
         if constexpr (COUNT) {
             const uint32_t ones = (uint32_t)__popcll(__ballot(val != 0));
             if (lane < 2) {
                 uint32_t *hp = reinterpret_cast<uint32_t *>(lds + h_addr + r.w[1]);
                 __hip_atomic_fetch_add(hp, (uint32_t)(h_sign * (int)ones + h_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (logrow && lane == 1) logrow[sidx] = (unsigned char)ones;
             }
         }
     };
@@ -234,16 +236,17 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
         __builtin_amdgcn_sched_barrier(0);
         uint32_t v0 = ph.c0 >= t0, v1 = ph.c1 >= t1, v2 = ph.c2 >= t2, v3 = ph.c3 >= t3;
         // commit in order; a step that reads what an earlier step of the quad wrote is recomputed first
+        const uint32_t s0 = qi * 4u;
         if (flags == 0) {
-            commit(R0, v0); commit(R1, v1); commit(R2, v2); commit(R3, v3);
+            commit(R0, v0, s0); commit(R1, v1, s0 + 1); commit(R2, v2, s0 + 2); commit(R3, v3, s0 + 3);
         } else {
-            commit(R0, v0);
+            commit(R0, v0, s0);
             if (flags & 1u) v1 = sample_rec<SLOTS, PACKED>(R1, st, lds, ph.c1);
-            commit(R1, v1);
+            commit(R1, v1, s0 + 1);
             if (flags & 2u) v2 = sample_rec<SLOTS, PACKED>(R2, st, lds, ph.c2);
-            commit(R2, v2);
+            commit(R2, v2, s0 + 2);
             if (flags & 4u) v3 = sample_rec<SLOTS, PACKED>(R3, st, lds, ph.c3);
-            commit(R3, v3);
+            commit(R3, v3, s0 + 3);
         }
         // next quad: plan words -> SGPRs -> record loads (scalar cache), then the plan of the quad after it
         __builtin_amdgcn_sched_barrier(0);
@@ -361,7 +364,8 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
 
     // commit the step slots whose level equals `pass`: write the new values, count them.
     // The 16 chains of a step slot are one DPP row: row_shr 1,2,4,8 leave the number of ones in lane 15.
-    auto commit = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine) {
+    unsigned char *logrow = p.log ? p.log + (size_t)(blockIdx.x * 4u + wave) * p.log_pitch + p.log_off : nullptr;
+    auto commit = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine, const uint32_t sidx) {
         if (mine) lds[r.h.x + cb] = (unsigned char)val;
         if constexpr (COUNT) {
             int s1 = (int)val;
@@ -373,6 +377,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
                 uint32_t *hp = reinterpret_cast<uint32_t *>(__builtin_assume_aligned(lds + r.h.y, 4));
                 __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(hp + 1, (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (logrow) logrow[sidx] = (unsigned char)s1;
             }
         }
     };
@@ -405,17 +410,18 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             for (int i = 0; i < (int)(sizeof(r.s) / sizeof(uint4)); ++i) r.s[i] = *reinterpret_cast<const uint4 *>(ra + 16 + 16 * i);
             const uint32_t lv = (pw[k] >> 1) & 3u;
             const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
+            const uint32_t sidx = (g0 + k) * 4u + j;
             uint32_t val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-            commit(r, val, lv == 0);
+            commit(r, val, lv == 0, sidx);
             if (maxlv >= 1) { // the quad has steps that do not commute: re-gather after the lower levels committed
                 val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-                commit(r, val, lv == 1);
+                commit(r, val, lv == 1, sidx);
                 if (maxlv >= 2) {
                     val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-                    commit(r, val, lv == 2);
+                    commit(r, val, lv == 2, sidx);
                     if (maxlv >= 3) {
                         val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-                        commit(r, val, lv == 3);
+                        commit(r, val, lv == 3, sidx);
                     }
                 }
             }

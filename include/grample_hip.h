@@ -208,6 +208,16 @@ int gr_active_groups(gr_sampler *s);
  * (chain.go:253-290) reads from ChainHistory.  (The reference's ring holds each variable's last
  * cw selections; here the halves are the two halves of the window in time.) */
 int gr_advance_window(gr_sampler *s, uint64_t updates_per_chain);
+/* Chain.AdvanceChain (chain.go:180-218) with its own stopping rule: batches of 2 N updates until every
+ * selectable variable has been selected cw + 1 more times -- evaluated per 64-chain scan group from the
+ * scan stream; every group then runs as long as the slowest one (out_updates, per chain).  For models
+ * whose selectable variables are all binary the kernels log every step's draw count and the two halves
+ * of every ChainHistory ring (the variable's last 2*(cw/2) selections, buffer/circular.go) are rebuilt
+ * exactly for gr_adapt / ChainConvergence; otherwise the halves are those of the window in time. */
+int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_updates);
+/* the half-window histograms kept by the last gr_advance_window / gr_advance_chain:
+ * first/second [n_variants * total_card] (inactive groups: zeros); *cw = the ConvergenceWindow they stand for */
+int gr_window_halves(gr_sampler *s, double *first, double *second, double *cw);
 /* ChainConvergence (chain.go:32-92) as a pure function: first/second [n_groups*total_card] half-window
  * histograms (any non-negative numbers; 1e-8 is added like ChainDist does), merged [total_card],
  * merged_collapsed [n_vars] (may be NULL), cw = ConvergenceWindow, measure 0 Hellinger / 1 JS /

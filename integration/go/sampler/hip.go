@@ -98,6 +98,16 @@ func NewHIPChains(m *model.Model, nChains, variants, device int, seed int64, bur
 	return c, nil
 }
 
+// AdvanceChain = for every chain: AdvanceChain + wg.Wait with the reference's stopping rule
+// (chain.go:184-215) for ConvergenceWindow cw; returns the updates each chain ran.
+func (c *HIPChains) AdvanceChain(cw int) (int64, error) {
+	var ran C.uint64_t
+	if C.gr_advance_chain(c.h, C.uint32_t(cw), &ran) != 0 {
+		return 0, lastErr()
+	}
+	return int64(ran), nil
+}
+
 // Advance = for every chain: AdvanceChain + wg.Wait, with an explicit length.
 func (c *HIPChains) Advance(updatesPerChain int64) error {
 	if C.gr_advance(c.h, C.uint64_t(updatesPerChain)) != 0 {

@@ -67,6 +67,7 @@ class Emulator:
         self.hoff = np.concatenate([[0], np.cumsum(card)]).astype(int)
         self.counts = np.zeros(int(sum(card)), dtype=np.uint64)
         self.step = 0
+        self.record = None  # list of (variable per chain, value per chain) per counted step when set to []
 
     def run(self, n_steps, counting):
         k0, k1 = self.seed & 0xFFFFFFFF, self.seed >> 32
@@ -84,11 +85,15 @@ class Emulator:
             dr = philox4x32_10(np.full(self.n_chains, ql), np.full(self.n_chains, qh), g.astype(np.uint32),
                                np.uint32(DOM_DRAW) + ((g >> np.uint64(32)).astype(np.uint32) << np.uint32(4)), k0, k1)[j]
             ks = mul_hi(sc, len(self.free))
+            vals = np.zeros(self.n_chains, dtype=np.int64)
             for c in range(self.n_chains):
                 v = self.free[int(ks[c])]
                 T = self.thr(v, self.state[:, c])
                 val = int(np.sum(np.uint64(dr[c]) >= T))
                 self.state[v, c] = val
+                vals[c] = val
                 if counting:
                     self.counts[self.hoff[v] + val] += np.uint64(1)
+            if counting and self.record is not None:
+                self.record.append((np.asarray([self.free[int(k)] for k in ks]), vals))
         self.step += n_steps

@@ -310,3 +310,107 @@ def test_many_chains_grouped_chain_per_lane_fast_path(res_dir):
     assert np.array_equal(ca, b.counts()) and np.array_equal(ca, d.counts())
     for c in (0, cpv + 7, K * cpv - 1):
         assert np.array_equal(a.LastSample(c), d.LastSample(c)) and np.array_equal(a.LastSample(c), b.LastSample(c))
+
+
+# ------------------------------------------- AdvanceChain: stopping rule + exact ChainHistory halves
+def _expected_rings(em, n, cw, groups):
+    """Replay chain.go:180-218 on the emulator: batches of 2N until every variable of every 64-chain group
+    was selected cw + 1 times; then the halves of every variable's ring (buffer/circular.go:54-84)."""
+    em.record = []
+    sel = np.zeros((groups, n), dtype=np.int64)
+    free = np.asarray(em.free)
+    batches = 0
+    while (sel[:, free] < cw + 1).any():
+        k0 = len(em.record)
+        em.run(2 * n, True)
+        for vs, _ in em.record[k0:]:
+            for gi in range(groups):
+                sel[gi, vs[gi * 64]] += 1
+        batches += 1
+    half = cw // 2
+    H = int(sum(em.card))
+    first, second = np.zeros(H), np.zeros(H)
+    for gi in range(groups):
+        hist = {int(v): [] for v in free}
+        for vs, vals in em.record:
+            hist[int(vs[gi * 64])].append(int(vals[gi * 64:(gi + 1) * 64].sum()))
+        for v, ones in hist.items():
+            ring = ones[-2 * half:]
+            assert len(ring) == 2 * half
+            for dst, part in ((first, ring[:half]), (second, ring[half:])):
+                dst[em.hoff[v] + 1] += sum(part)
+                dst[em.hoff[v]] += 64 * half - sum(part)
+    return batches * 2 * n, first, second
+
+
+@pytest.mark.parametrize("model,cw,chains,flags,path", [
+    ("grid3x3", 6, 192, 0, 3),
+    ("grid3x3", 7, 192, g.GR_FLAG_CHAIN_PER_LANE, 2),
+    ("grid3x3", 6, 128, g.GR_FLAG_DIRECT, 0),
+    ("Grids_11.uai", 2, 64, 0, 3),
+])
+def test_advance_chain_stop_rule_and_rings_vs_emulator(res_dir, model, cw, chains, flags, path):
+    from tests import exact_chain
+    from tests.emulator import Emulator
+    from tests.test_gpu_parity import _thresholds_from_device, _gm
+    pm = uai_py.load(res_dir, model) if model.endswith(".uai") else exact_chain.tiny_models()[model]
+    n = len(pm.card)
+    s = g.HIPChains(_gm(pm), chains, seed=77, flags=flags)
+    assert s.info()["path"] == path
+    free = [v for v in range(n) if pm.fixed[v] < 0]
+    em = Emulator(pm.card, pm.fixed, free, _thresholds_from_device(s, pm.card), chains, 77)
+    s.BurnIn(13); em.run(13, False)  # quad-unaligned start of the window
+    L = s.AdvanceChain(cw)
+    eL, efirst, esecond = _expected_rings(em, n, cw, chains // 64)
+    assert L == eL
+    assert np.array_equal(s.counts()[0], em.counts)
+    a, b, got_cw = s.window_halves()
+    assert got_cw == cw
+    assert np.array_equal(a[0], efirst) and np.array_equal(b[0], esecond)
+    assert s.TotalSampleCount() == chains * L and s.info()["step"] == 13 + L
+    # a second window continues from where the first one stopped
+    L2 = s.AdvanceChain(cw)
+    eL2, efirst2, esecond2 = _expected_rings(em, n, cw, chains // 64)
+    a2, b2, _ = s.window_halves()
+    assert L2 == eL2 and np.array_equal(a2[0], efirst2) and np.array_equal(b2[0], esecond2)
+
+
+def test_advance_chain_adaptive_flow_and_fallbacks(res_dir):
+    """`--sampler adaptive` with the reference's own window length (root.go:476-479 -> chain.go:180-218):
+    ring halves are per group, groups activated later get theirs, and a model with Card > 2 falls back to the
+    halves of the window in time."""
+    name = "Segmentation_11.uai"
+    pm = uai_py.load(res_dir, name)
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    n, K, cpv, cw = len(pm.card), 8, 128, 10
+    s = g.HIPChains.NewGibbsCollapsed(gm, K * cpv, K, seed=5)
+    s.set_active_groups(2)
+    s.BurnIn(3 * n)
+    sizes = []
+    for rnd in range(3):
+        L = s.AdvanceChain(cw)
+        assert L % (2 * n) == 0 and L >= (cw + 1) * n
+        a, b, _ = s.window_halves()
+        act = s.active_groups()
+        # every active group: each selectable variable holds exactly cw/2 selections x chains in either half
+        hs = np.concatenate([[0], np.cumsum(pm.card)])
+        for k in range(act):
+            per_var = np.add.reduceat(a[k], hs[:-1]), np.add.reduceat(b[k], hs[:-1])
+            for pv in per_var:
+                assert set(np.unique(pv).tolist()) <= {0.0, float(cpv * (cw // 2))}
+                assert (pv == 0).sum() == (0 if k < 2 else 1)  # the group's collapsed variable is never selected
+        assert not a[act:].any() and not b[act:].any()
+        new, conv = s.Adapt(3)
+        sizes.append(s.active_groups())
+    assert sizes == [5, 8, 8]
+    assert int(s.counts().sum()) == s.TotalSampleCount()
+    # Card 16: no draw log -> halves in time, still the reference's stopping rule
+    pm2 = uai_py.load(res_dir, "ObjectDetection_13.uai")
+    s2 = g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, "ObjectDetection_13.uai")), 128, seed=5)
+    L = s2.AdvanceChain(4)
+    a, b, _ = s2.window_halves()
+    assert L % (2 * len(pm2.card)) == 0 and a.sum() + b.sum() == 128 * L
+    with pytest.raises(g.GrError):
+        g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai")), 64, flags=g.GR_FLAG_SCAN_PER_CHAIN).AdvanceChain(4)
+    with pytest.raises(g.GrError):
+        g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai")), 70).AdvanceChain(4)

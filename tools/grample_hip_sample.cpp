@@ -7,7 +7,8 @@
 // front end; this is the compiled-language host the image can build (no Go here).
 //
 //   grample_hip_sample -m MODEL.uai [-s simple|collapsed|adaptive] [-o] [-d] [-c CHAINS] [-k GROUPS]
-//                      [-b BURNIN] [-i MAXITERS] [-r ROUNDS] [-e SEED] [--device N]
+//                      [-b BURNIN] [-i MAXITERS] [-r ROUNDS] [-w CWIN] [-e SEED] [--device N]
+//   -w CWIN: every round is one Chain.AdvanceChain with ConvergenceWindow CWIN (chain.go:180-218) instead of MAXITERS/ROUNDS updates
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -26,7 +27,7 @@ static void die(const char *what) {
 int main(int argc, char **argv) {
     std::string model, samp = "simple";
     bool use_evidence = false, use_solution = false;
-    long chains = 65536, groups = 0, burnin = -1, maxiters = -1, rounds = 10, seed = 42;
+    long chains = 65536, groups = 0, burnin = -1, maxiters = -1, rounds = 10, seed = 42, cwin = 0;
     int device = 0;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -40,6 +41,7 @@ int main(int argc, char **argv) {
         else if (a == "-b" || a == "--burnin") burnin = std::atol(next());
         else if (a == "-i" || a == "--maxiters") maxiters = std::atol(next());
         else if (a == "-r" || a == "--rounds") rounds = std::atol(next());
+        else if (a == "-w" || a == "--cwin") cwin = std::atol(next());
         else if (a == "-e" || a == "--seed") seed = std::atol(next());
         else if (a == "--device") device = std::atoi(next());
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
@@ -97,7 +99,11 @@ int main(int argc, char **argv) {
     const uint64_t per_round = (uint64_t)std::max(1L, maxiters / std::max(1L, rounds));
     double es[8];
     for (long r = 0; r < rounds; ++r) {
-        if (adaptive ? gr_advance_window(s, per_round) : gr_advance(s, per_round)) die("Async sample generation failed");
+        if (cwin > 0) {
+            uint64_t ran = 0;
+            if (gr_advance_chain(s, (uint32_t)cwin, &ran)) die("Async sample generation failed");
+            if (r == 0) std::printf("  AdvanceChain(cw=%ld) ran %llu updates per chain\n", cwin, (unsigned long long)ran);
+        } else if (adaptive ? gr_advance_window(s, per_round) : gr_advance(s, per_round)) die("Async sample generation failed");
         uint64_t samples = 0;
         gr_total_samples(s, &samples);
         gr_sampler *one[1] = {s};
