@@ -54,7 +54,10 @@ COND_ABS, COND_REL = 4e-10, 5e-5
                                      ("Pedigree_11.uai", True), ("CSP_12.uai", False),
                                      ("ObjectDetection_11.uai", False),  # Card 11 < the kernel's 16-wide rows
                                      ("Alchemy_11.uai", False),          # blankets up to 60 variables, arity 3
-                                     ("dv-rel_2.uai", True)])            # 1200 variables, arity 4, 307 evidence variables
+                                     ("dv-rel_2.uai", True),             # 1200 variables, arity 4, 307 evidence variables
+                                     ("dv-rel_3.uai", True),             # arity 10, 1024-entry tables (400 KB of tables: not LDS-resident)
+                                     ("CSP_13.uai", False),              # Card 4, 31 factors on one variable
+                                     ("Promedus_17.uai", True)])         # 916 variables
 def test_conditional_matches_oracle(oracle, res_dir, name, ev):
     """a4-a8: gather + log-sum + stabilise/exp/floor + normalise (gibbs-simple.go:175-258)."""
     pm = uai_py.load(res_dir, name, ev)
@@ -65,15 +68,24 @@ def test_conditional_matches_oracle(oracle, res_dir, name, ev):
     s = g.HIPChains.NewGibbsSimple(g.Model.NewModelFromFile(os.path.join(res_dir, name), ev), 64)
     rng = np.random.default_rng(0)
     free = [v for v in range(len(pm.card)) if pm.fixed[v] < 0]
-    hit_floor = 0
+    hit_floor = knife = 0
     for _ in range(300):
         st = np.array([rng.integers(0, c) if f < 0 else f for c, f in zip(pm.card, pm.fixed)], dtype=np.int32)
         v = int(rng.choice(free))
         pd = s.conditional(0, v, st)
         po = _oracle_cond(oracle, osamp, v, st, pm.card[v])
         assert abs(pd.sum() - 1.0) < 1e-12
-        assert np.all(np.abs(pd - po) <= COND_ABS + COND_REL * po), (name, v, pd, po)
+        bad = np.abs(pd - po) > COND_ABS + COND_REL * po
+        if bad.any():
+            # Knife edge of the floor rule (gibbs-simple.go:247-255): a value whose probability is 1e-6 up to
+            # rounding (tables written with literal 1e-06 entries, e.g. Promedus) is floored, i.e. doubled to
+            # 2e-6, or not, depending on the last bits of exp/log -- in f64 as much as in f32.
+            # Either outcome is accepted there and nowhere else.
+            edge = lambda p: np.minimum(np.abs(p / 1e-6 - 1.0), np.abs(p / 2e-6 - 1.0)) < 2e-4
+            assert np.all(edge(pd[bad]) & edge(po[bad])), (name, v, pd, po)
+            knife += 1
         hit_floor += int(po.min() < 2e-6)
+    assert knife <= 15, (name, knife)
     if name == "Grids_13.uai":
         assert hit_floor > 10  # the 1e-6 floor is exercised (tables span 5.5e-5 .. 1.8e4)
     fx = [v for v in range(len(pm.card)) if pm.fixed[v] >= 0]
@@ -215,7 +227,9 @@ def _group_props(counts, cards):
                                                         ("CSP_12.uai", 10, 30, 8, False),      # Card 4, arity 3
                                                         ("Promedus_11.uai", 5, 15, 4, True),   # evidence, binary, arity 3
                                                         ("ObjectDetection_11.uai", 10, 30, 8, False),  # Card 11
-                                                        ("Alchemy_11.uai", 5, 10, 4, False)])  # blankets up to 60
+                                                        ("Alchemy_11.uai", 5, 10, 4, False),   # blankets up to 60
+                                                        ("dv-rel_3.uai", 4, 8, 2, True),       # arity 10, tables in HBM/L2
+                                                        ("CSP_13.uai", 10, 30, 8, False)])     # Card 4, degree 31
 def test_marginals_match_oracle_runs(oracle, res_dir, name, burn_sw, upd_sw, per, ev):
     """Two-sample test, oracle (MT19937-64, f64, Go semantics) vs GPU (Philox, f32 tables): same
     burn-in and update counts per chain.  Both sides are run as G independent groups; a group's
