@@ -484,77 +484,132 @@ __global__ void __launch_bounds__(256) k_collapse(const CollapseArgs a) {
 
 // ------------------------------------------------------------ scan-stream kernels
 // The variable a 64-chain group updates at step s (same arithmetic as k_sweep / k_scan_plan).
+// One wavefront replays the scan stream of one 64-chain group: lane l draws the Philox block of quad q0 + l.
 struct ScanReplay {
-    const ScanArgs &a;
     const uint32_t *freev;
-    uint32_t n_free, gid;
-    uint64_t cached_q = ~0ull;
-    u32x4 w{};
-    __device__ ScanReplay(const ScanArgs &args, uint32_t group) : a(args) {
+    uint32_t n_free, gid, seed_lo, seed_hi;
+    __device__ ScanReplay(const ScanArgs &a, uint32_t group) {
         const VariantDesc vd = a.variants[(group * 64u) / a.chains_per_variant];
         freev = a.free_vars + vd.free_base;
         n_free = vd.n_free;
         const uint64_t gchain0 = (((uint64_t)a.chain_offset_hi << 32) | a.chain_offset_lo) + (uint64_t)group * 64u;
         gid = (uint32_t)(gchain0 >> 6);
+        seed_lo = a.seed_lo; seed_hi = a.seed_hi;
     }
-    __device__ uint32_t var_at(uint64_t s) {
-        const uint64_t q = s >> 2;
-        if (q != cached_q) {
-            w = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), gid, DOM_SCAN, a.seed_lo, a.seed_hi);
-            cached_q = q;
-        }
-        const uint32_t j = (uint32_t)(s & 3u);
-        const uint32_t r = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
-        return freev[mul_hi_u32(r, n_free)];
+    // the four variables of quad q (steps 4q .. 4q+3)
+    __device__ void quad(uint64_t q, uint32_t v[4]) const {
+        const u32x4 w = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), gid, DOM_SCAN, seed_lo, seed_hi);
+        v[0] = freev[mul_hi_u32(w.x, n_free)]; v[1] = freev[mul_hi_u32(w.y, n_free)];
+        v[2] = freev[mul_hi_u32(w.z, n_free)]; v[3] = freev[mul_hi_u32(w.w, n_free)];
     }
 };
 
 // AdvanceChain's stopping rule (chain.go:184-215): batches of `batch` (= 2 N) updates until every selectable
 // variable of the group has been selected cw + 1 more times.  out[group] = number of batches.
-__global__ void k_stop_time(const ScanArgs a, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *counts /*[n_groups][n_vars]*/,
-                            uint32_t *out) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.n_groups) return;
-    ScanReplay sr(a, g);
-    uint32_t *cnt = counts + (size_t)g * a.n_vars;
-    for (uint32_t i = 0; i < sr.n_free; ++i) cnt[sr.freev[i]] = 0;
-    uint32_t remaining = sr.n_free, b = 0;
+// One wavefront per group; selection counters in LDS (n_vars words).
+__global__ __launch_bounds__(64) void k_stop_time(const ScanArgs a, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *out) {
+    extern __shared__ uint32_t sm_scan[];
+    uint32_t *cnt = sm_scan;
+    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    const ScanReplay sr(a, g);
+    for (uint32_t v = lane; v < a.n_vars; v += 64u) cnt[v] = 0;
+    __syncthreads();
+    // (cw + 1) * n_free selections are needed in all: no batch before that many steps can be the last one
+    const uint64_t need_steps = (uint64_t)(cw + 1u) * sr.n_free;
     uint64_t s = ((uint64_t)a.step0_hi << 32) | a.step0_lo;
-    while (b < max_batches && remaining) {
-        for (uint32_t i = 0; i < batch; ++i, ++s) {
-            const uint32_t v = sr.var_at(s);
-            if (++cnt[v] == cw + 1u) remaining--;
+    uint32_t b = 0;
+    bool done = sr.n_free == 0;
+    while (b < max_batches && !done) {
+        const uint64_t e = s + batch;
+        for (uint64_t q = (s >> 2) + lane; q <= ((e - 1u) >> 2); q += 64u) {
+            uint32_t v[4];
+            sr.quad(q, v);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint64_t st = q * 4u + j;
+                if (st >= s && st < e) atomicAdd(&cnt[v[j]], 1u);
+            }
         }
+        s = e;
         b++;
+        __syncthreads();
+        if ((uint64_t)b * batch >= need_steps) {
+            bool need = false;
+            for (uint32_t i = lane; i < sr.n_free; i += 64u) need = need || cnt[sr.freev[i]] < cw + 1u;
+            done = __ballot(need) == 0ull;
+        }
     }
-    out[g] = remaining ? 0xffffffffu : b;
+    if (lane == 0) out[g] = done ? b : 0xffffffffu;
 }
 
 // ChainHistory's two halves (buffer/circular.go:54-84, chain.go:270-277), rebuilt from the draw log: walking the
 // window backwards, the newest `half` selections of a variable are its second half, the `half` before them its
 // first half.  ones[g][h][v] = number of chains that drew 1 in half h; status[g] = variables whose ring is not full.
-__global__ void k_ring_halves(const ScanArgs a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
-                              uint32_t *seen /*[n_groups][n_vars]*/, uint32_t *ones /*[n_groups][2][n_vars]*/, uint32_t *status) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.n_groups) return;
-    ScanReplay sr(a, g);
-    uint32_t *sn = seen + (size_t)g * a.n_vars;
-    uint32_t *o1 = ones + (size_t)g * 2u * a.n_vars; // first half
-    uint32_t *o2 = o1 + a.n_vars;                     // second half
-    for (uint32_t i = 0; i < sr.n_free; ++i) { const uint32_t v = sr.freev[i]; sn[v] = 0; o1[v] = 0; o2[v] = 0; }
-    const uint64_t step0 = ((uint64_t)a.step0_hi << 32) | a.step0_lo;
-    uint32_t remaining = sr.n_free;
-    for (uint32_t k = n_steps; k-- > 0 && remaining;) {
-        const uint32_t v = sr.var_at(step0 + k);
-        const uint32_t c = sn[v];
-        if (c >= 2u * half) continue;
-        uint32_t n1 = 0;
-        for (uint32_t r = 0; r < log_rows; ++r) n1 += log[((size_t)g * log_rows + r) * log_pitch + k];
-        if (c < half) o2[v] += n1; else o1[v] += n1;
-        sn[v] = c + 1u;
-        if (c + 1u == 2u * half) remaining--;
+// One wavefront per group, 256 steps at a time: (0) every lane replays one quad of the scan stream and stages
+// (variable, ones) per step in LDS; (1) every lane lists, newest first, the steps whose variable it owns
+// (v mod 64 == lane); (2) the lanes walk their lists side by side -- a variable is only ever touched by its owner,
+// so the per-variable order of the serial walk is kept without atomics.
+__global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch,
+                                                     uint32_t log_rows, uint32_t *ones /*[n_groups][2][n_vars]*/, uint32_t *status) {
+    extern __shared__ uint32_t sm_scan[];
+    const uint32_t n = a.n_vars, g = blockIdx.x, lane = threadIdx.x;
+    uint32_t *sn = sm_scan, *o1 = sn + n, *o2 = o1 + n, *rem = o2 + n;
+    unsigned short *cv = reinterpret_cast<unsigned short *>(rem + 1);
+    unsigned short *cl = cv + 256;
+    unsigned char *list = reinterpret_cast<unsigned char *>(cl + 256) + lane * 256u;
+    const ScanReplay sr(a, g);
+    for (uint32_t v = lane; v < n; v += 64u) { sn[v] = 0; o1[v] = 0; o2[v] = 0; }
+    if (lane == 0) *rem = sr.n_free;
+    __syncthreads();
+    const int64_t step0 = (int64_t)(((uint64_t)a.step0_hi << 32) | a.step0_lo);
+    const unsigned char *lg = log + (size_t)g * log_rows * log_pitch;
+    int64_t e = half ? (int64_t)n_steps : 0; // steps [0, e) of the window are still to be visited
+    while (e > 0 && *rem) {
+        const int64_t qhi = (step0 + e - 1) >> 2, qlo = qhi - 63;
+        { // (0) stage the chunk
+            const int64_t q = qlo + lane;
+            uint32_t v[4] = {0, 0, 0, 0};
+            if (q >= 0) sr.quad((uint64_t)q, v);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const int64_t k = q * 4 + j - step0;
+                const bool valid = k >= 0 && k < e;
+                uint32_t n1 = 0;
+                if (valid) for (uint32_t r = 0; r < log_rows; ++r) n1 += lg[(size_t)r * log_pitch + (size_t)k];
+                cv[lane * 4u + j] = valid ? (unsigned short)v[j] : (unsigned short)0xffffu;
+                cl[lane * 4u + j] = (unsigned short)n1;
+            }
+        }
+        __syncthreads();
+        uint32_t mine = 0; // (1) my steps, newest first
+        for (int idx = 255; idx >= 0; --idx) {
+            const uint32_t v = cv[idx];
+            if (v != 0xffffu && (v & 63u) == lane) list[mine++] = (unsigned char)idx;
+        }
+        uint32_t most = mine;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, o));
+        uint32_t full = 0;
+        for (uint32_t k = 0; k < most; ++k) { // (2)
+            if (k < mine) {
+                const uint32_t idx = list[k], v = cv[idx], c = sn[v];
+                if (c < 2u * half) {
+                    if (c < half) o2[v] += cl[idx]; else o1[v] += cl[idx];
+                    sn[v] = c + 1u;
+                    full += (c + 1u == 2u * half) ? 1u : 0u;
+                }
+            }
+        }
+        if (full) atomicSub(rem, full);
+        __syncthreads();
+        e = qlo * 4 - step0; // everything from quad qlo on is done
     }
-    status[g] = remaining;
+    __syncthreads();
+    for (uint32_t v = lane; v < n; v += 64u) {
+        ones[((size_t)g * 2u + 0u) * n + v] = o1[v];
+        ones[((size_t)g * 2u + 1u) * n + v] = o2[v];
+    }
+    if (lane == 0) status[g] = half ? *rem : 0u;
 }
 
 // ------------------------------------------------------------ host launchers
@@ -621,14 +676,15 @@ hipError_t launch_conditional(const VariantDesc &vd, const uint32_t *progs, cons
     return hipGetLastError();
 }
 
-hipError_t launch_stop_time(const ScanArgs &a, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *counts, uint32_t *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_stop_time, dim3((a.n_groups + 63) / 64), dim3(64), 0, s, a, cw, batch, max_batches, counts, out);
+hipError_t launch_stop_time(const ScanArgs &a, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_stop_time, dim3(a.n_groups), dim3(64), a.n_vars * sizeof(uint32_t), s, a, cw, batch, max_batches, out);
     return hipGetLastError();
 }
 
 hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
-                              uint32_t *seen, uint32_t *ones, uint32_t *status, hipStream_t s) {
-    hipLaunchKernelGGL(k_ring_halves, dim3((a.n_groups + 63) / 64), dim3(64), 0, s, a, n_steps, half, log, log_pitch, log_rows, seen, ones, status);
+                              uint32_t *ones, uint32_t *status, hipStream_t s) {
+    const size_t lds = (3u * (size_t)a.n_vars + 1u) * sizeof(uint32_t) + 2u * 256u * sizeof(unsigned short) + 64u * 256u;
+    hipLaunchKernelGGL(k_ring_halves, dim3(a.n_groups), dim3(64), lds, s, a, n_steps, half, log, log_pitch, log_rows, ones, status);
     return hipGetLastError();
 }
 

@@ -1028,10 +1028,9 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         // 1. how long: batches of 2N updates until every variable of every group has cw + 1 new samples (chain.go:184-215)
         const uint32_t batch = 2u * (uint32_t)s->n_vars;
         const uint32_t max_batches = (uint32_t)std::min<uint64_t>((1ull << 31) / batch, 1u << 20);
-        DevBuf<uint32_t> d_cnt, d_out;
-        d_cnt.alloc((size_t)n_groups * s->n_vars);
+        DevBuf<uint32_t> d_out;
         d_out.alloc(n_groups);
-        hip_check(launch_stop_time(a, cw, batch, max_batches, d_cnt.p, d_out.p, s->stream), "k_stop_time");
+        hip_check(launch_stop_time(a, cw, batch, max_batches, d_out.p, s->stream), "k_stop_time");
         std::vector<uint32_t> nb(n_groups);
         hip_check(hipMemcpyAsync(nb.data(), d_out.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
         s->sync();
@@ -1074,11 +1073,10 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         if (logging) {
             // 3. rebuild every ring's halves: the last 2 * (cw / 2) selections of each variable (circular.go:16-28)
             const uint32_t half = cw / 2u;
-            DevBuf<uint32_t> d_seen, d_ones, d_status;
-            d_seen.alloc((size_t)n_groups * s->n_vars);
+            DevBuf<uint32_t> d_ones, d_status;
             d_ones.alloc((size_t)n_groups * 2u * s->n_vars);
             d_status.alloc(n_groups);
-            hip_check(launch_ring_halves(a, (uint32_t)L, half, d_log.p, (uint32_t)pitch, rows, d_seen.p, d_ones.p, d_status.p, s->stream), "k_ring_halves");
+            hip_check(launch_ring_halves(a, (uint32_t)L, half, d_log.p, (uint32_t)pitch, rows, d_ones.p, d_status.p, s->stream), "k_ring_halves");
             std::vector<uint32_t> ones((size_t)n_groups * 2u * s->n_vars), status(n_groups);
             hip_check(hipMemcpyAsync(ones.data(), d_ones.p, ones.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
             hip_check(hipMemcpyAsync(status.data(), d_status.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
