@@ -162,6 +162,23 @@ def test_sweep_bitwise_vs_numpy_emulator(res_dir, name, ev, chains, steps, flags
     assert s.info()["step"] == burn + steps
 
 
+@pytest.mark.parametrize("kw", [dict(), dict(fast_form=1), dict(flags=g.GR_FLAG_DIRECT), dict(flags=g.GR_FLAG_SCAN_PER_CHAIN)])
+def test_bitwise_with_64bit_chain_offset_and_seed(res_dir, kw):
+    """Global chain ids and seeds above 2^32 reach the Philox counter / key words intact in every kernel form
+    (a sharded job numbers its chains globally: chain_offset = rank * chains_per_rank)."""
+    name, chains, off, seed = "Grids_11.uai", 128, (1 << 40) + 64 * 7, (0xDEADBEEF << 32) | 0x12345678
+    pm = uai_py.load(res_dir, name)
+    s = g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, name)), chains, seed=seed, chain_offset=off, **kw)
+    em = Emulator(pm.card, pm.fixed, list(range(len(pm.card))), _thresholds_from_device(s, pm.card), chains, seed, chain_offset=off,
+                  per_chain=bool(kw.get("flags", 0) & g.GR_FLAG_SCAN_PER_CHAIN))
+    assert np.array_equal(s.LastSample(chains - 1), em.state[:, chains - 1])
+    s.BurnIn(7); em.run(7, False)
+    s.Advance(90); em.run(90, True)
+    assert np.array_equal(s.counts()[0], em.counts)
+    for c in (0, 64, chains - 1):
+        assert np.array_equal(s.LastSample(c), em.state[:, c])
+
+
 def test_all_kernel_forms_agree_bit_for_bit(res_dir):
     """Grids_13: direct (0), memoised (1), chain per lane (2) and 4 lanes per chain (3) are the same process:
     identical histograms and states after quad-unaligned burn-in and advance."""
