@@ -41,6 +41,7 @@ hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half
                               uint32_t *ones, uint32_t *status, hipStream_t s);
 // fast binary / memoised path (sweep_bin.hip)
 hipError_t launch_scan_plan(const FastParams &p, hipStream_t s);
+hipError_t launch_sweep_strict(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s);
 hipError_t launch_sweep_bin(const FastParams &p, int slots, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s);
 hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t lds, hipStream_t s);
 constexpr uint32_t kParStateStride = 80; // must match kParStride in sweep_bin.hip

@@ -105,6 +105,7 @@ struct gr_sampler {
     bool par_packed = false;          // step-parallel records use one dword per neighbour
     uint32_t rec_stride = 64;         // bytes per record (128 when a variable has 13..16 neighbours)
     bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
+    bool strict_fast = false;         // GR_FLAG_SCAN_PER_CHAIN on memoised tables (k_sweep_strict, the 4-lane form's LDS layout)
     uint32_t par_hist_off = 0, par_tab_off = 0, par_rec_off = 0, par_plan_off = 0, par_scr_off = 0, par_lds = 0;
     // device pools
     DevBuf<VariantDesc> d_variants;
@@ -139,6 +140,7 @@ struct gr_sampler {
     void sync() { hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
 
     void configure();
+    void configure_impl(bool try_strict_fast);
     void rebuild();
     void init_state(uint32_t variant);
     void run(uint64_t updates, bool counting);
@@ -147,9 +149,23 @@ struct gr_sampler {
 
 // Pick block size, LDS layout and conditional path for the current images.
 void gr_sampler::configure() {
+    strict_fast = false;
+    if ((o.flags & GR_FLAG_SCAN_PER_CHAIN) && !(o.flags & GR_FLAG_DIRECT)) {
+        // strict mode first tries the memoised tables in the 4-lane form's LDS layout (k_sweep_strict)
+        try {
+            configure_impl(true);
+        } catch (const Error &) {
+            par = false;
+        }
+        if (par) { strict_fast = true; return; }
+    }
+    configure_impl(false);
+}
+
+void gr_sampler::configure_impl(bool try_strict_fast) {
     cpv = o.n_chains / o.n_variants;
     uint32_t views_max = 0, cpt_max = 0;
-    bool all_cpt = !(o.flags & (GR_FLAG_DIRECT | GR_FLAG_SCAN_PER_CHAIN));
+    bool all_cpt = !(o.flags & GR_FLAG_DIRECT) && (try_strict_fast || !(o.flags & GR_FLAG_SCAN_PER_CHAIN));
     for (const auto &im : image) {
         views_max = std::max<uint32_t>(views_max, (uint32_t)im.views.size());
         cpt_max = std::max<uint32_t>(cpt_max, (im.cpt_words + 3u) & ~3u);
@@ -220,7 +236,7 @@ void gr_sampler::configure() {
                 // a single wavefront (measured on Grids_13: 4.9e11 vs 4.1e11 updates/s at 65 536 chains,
                 // 5.0e11 vs 6.2e11 at 131 072)
                 par = false;
-                const uint32_t form = o.fast_form; // 0 auto, 1 chain per lane, 2 four lanes per chain
+                const uint32_t form = try_strict_fast ? 2u : o.fast_form; // 0 auto, 1 chain per lane, 2 four lanes per chain
                 if (fast_ok && use_cpt && tl && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && form != 1 &&
                     (form == 2 || o.n_chains / 64u <= 1536u || !cpl_fast)) {
                     uint32_t nfree_max = 0;
@@ -394,7 +410,10 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
             p.n_steps = n;
             p.log = cur_log; p.log_pitch = cur_log_pitch; p.log_rows = cur_log_rows; p.log_off = (uint32_t)(step - cur_log_step0);
-            hip_check(launch_sweep(p, max_card, cpt, tab_lds, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, (act + T - 1) / T, T, lds, stream), "k_sweep launch");
+            // strict mode runs the direct arithmetic (bit-identical to the memoised tables); with strict_fast the LDS table
+            // area holds thresholds, so the views are read from global memory
+            hip_check(launch_sweep(p, max_card, cpt && !strict_fast, tab_lds && !strict_fast, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0,
+                                   (act + T - 1) / T, T, lds, stream), "k_sweep launch");
             step += n;
             left -= n;
             launches_last++;
@@ -426,7 +445,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.counting = p.counting; f.lds_hist_off = lds_hist_off; f.lds_tab_off = lds_tab_off; f.lds_plan_off = lds_plan_off;
         f.recs_par = d_recs_par.p; f.par_hist_off = par_hist_off; f.par_tab_off = par_tab_off; f.par_rec_off = par_rec_off;
         f.par_plan_off = par_plan_off; f.par_scr_off = par_scr_off;
-        const uint64_t gran = par ? 16 : 4; // steps per inner iteration of the fast kernels
+        const uint64_t gran = strict_fast ? 4 : par ? 16 : 4; // steps per inner iteration of the fast kernels
         uint64_t left = updates;
         const uint64_t head = std::min<uint64_t>(left, (gran - (step % gran)) % gran);
         if (head) { generic_small(head); left -= head; }
@@ -435,6 +454,18 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
             f.n_steps = n;
             f.log = cur_log; f.log_pitch = cur_log_pitch; f.log_off = (uint32_t)(step - cur_log_step0);
+            if (strict_fast) {
+                // 4 waves per block share tables and records once there are more 64-chain groups than the chip holds
+                // as single-wave blocks (LDS limits a CU to ~4 blocks)
+                const uint32_t region = (((uint32_t)n_vars * kParStateStride) + 15u) & ~15u;
+                const bool quad_blocks = act % 256u == 0 && act / 64u > 1024u && (o.n_variants == 1 || cpv % 256u == 0) &&
+                                         par_lds + 3u * region <= kLdsBudget;
+                f.strict_state_off = par_lds;
+                hip_check(launch_sweep_strict(f, fast_slots, par_packed, quad_blocks ? act / 256u : act / 64u, quad_blocks ? 256u : 64u,
+                                              quad_blocks ? par_lds + 3u * region : par_lds, stream), "k_sweep_strict launch");
+                step += n; left -= n; launches_last++;
+                continue;
+            }
             hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
             if (par) hip_check(launch_sweep_par4(f, fast_slots, par_packed, act / 64u, par_lds, stream), "k_sweep_par4 launch");
             else hip_check(launch_sweep_bin(f, fast_slots, act / T, T, lds, stream), "k_sweep_bin launch");
@@ -475,7 +506,7 @@ void gr_sampler::burn_group(uint32_t group, uint32_t updates) {
     p.n_steps = updates; p.counting = 0; p.sequential = 0;
     p.lds_hist_off = lds_hist_off; p.lds_tab_off = lds_tab_off;
     const uint32_t t = std::min(T, 256u);
-    hip_check(launch_sweep(p, max_card, cpt, tab_lds, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, (cpv + t - 1) / t, t, lds, stream),
+    hip_check(launch_sweep(p, max_card, cpt && !strict_fast, tab_lds && !strict_fast, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, (cpv + t - 1) / t, t, lds, stream),
               "k_sweep launch (group burn-in)");
     sync();
 }
@@ -1276,7 +1307,7 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         if (!s || !out || out->struct_size != sizeof(gr_sampler_info)) throw Error(GR_E_INVALID, "bad gr_sampler_info");
         if (s->dirty) { s->use(); s->configure(); }
         out->block_threads = s->T; out->n_blocks = s->blocks; out->lds_bytes = s->lds;
-        out->path = s->fast ? (s->par ? 3u : 2u) : (s->cpt ? 1u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
+        out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->cpt ? 1u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

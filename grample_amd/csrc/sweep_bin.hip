@@ -440,6 +440,103 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     }
 }
 
+// K1, strict form (GR_FLAG_SCAN_PER_CHAIN): every chain draws its own variable at every step, exactly like
+// UniformSampler.VarSample (sampler/sampler.go:135-174) -- no wave-uniform scan, hence no scan plan and no
+// scalar records.  One chain per lane, one 64-chain wavefront per block, the 4-lane form's LDS layout
+// (80-byte state rows, records and threshold tables in LDS, read per lane); two Philox blocks per quad
+// (DOM_SCAN_CHAIN for the variables, DOM_DRAW for the values); per-lane LDS atomics for the histogram.
+// Steps of a chain are sequential, so nothing needs re-gathering.  Bit-identical to the generic
+// kernel's strict mode (k_sweep<.., PC = true>), which handles quad-unaligned heads and tails.
+template <int SLOTS, bool PACKED, bool COUNT>
+__global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    // 1 or 4 wavefronts per block share the tables and records; wave 0 keeps its 64 chains in the layout's state
+    // region at offset 0, waves 1..3 in extra regions behind the 4-lane form's layout (p.strict_state_off)
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, T = blockDim.x;
+    const uint32_t chain = blockIdx.x * T + tid;
+    const uint32_t variant = (blockIdx.x * T) / p.chains_per_variant;
+    const VariantDesc vd = p.variants[variant];
+    unsigned char *st = lds + (wave ? p.strict_state_off + (wave - 1u) * (((p.n_vars * kParStride) + 15u) & ~15u) : 0u) + lane;
+    {
+        const uint32_t n4 = (vd.cpt_len + 3u) >> 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + p.par_tab_off);
+        for (uint32_t i = tid; i < n4; i += T) dst[i] = src[i];
+        const uint4 *rs = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.recs_par) + (size_t)vd.rec_base * p.rec_stride);
+        uint4 *rd = reinterpret_cast<uint4 *>(lds + p.par_rec_off);
+        for (uint32_t i = tid; i < vd.n_free * (p.rec_stride / 16u); i += T) rd[i] = rs[i];
+        for (uint32_t v = 0; v < p.n_vars; ++v) st[v * kParStride] = p.state[(size_t)v * p.pitch + chain];
+        uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
+        for (uint32_t i = tid; i < p.H; i += T) h[i] = 0;
+    }
+    __syncthreads();
+    const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
+    const uint32_t g_lo = (uint32_t)gchain, g_hi4 = (uint32_t)(gchain >> 32) << 4;
+    const uint64_t q0 = (((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2;
+    const uint32_t nq = p.n_steps >> 2;
+    const unsigned char *recs = lds + p.par_rec_off;
+    for (uint32_t qi = 0; qi < nq; ++qi) {
+        const uint64_t q = q0 + qi;
+        const u32x4 sc = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), g_lo, DOM_SCAN_CHAIN + g_hi4, p.seed_lo, p.seed_hi);
+        const u32x4 dr = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), g_lo, DOM_DRAW + g_hi4, p.seed_lo, p.seed_hi);
+        const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w}, du[4] = {dr.x, dr.y, dr.z, dr.w};
+        RecL<SLOTS, PACKED> r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { // the records only depend on the scan stream: fetch all four first
+            const unsigned char *ra = recs + mul_hi_u32(su[j], vd.n_free) * p.rec_stride;
+            r[j].h = *reinterpret_cast<const uint4 *>(ra);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(r[j].s) / sizeof(uint4)); ++i) r[j].s[i] = *reinterpret_cast<const uint4 *>(ra + 16 + 16 * i);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t val = sample_l<SLOTS, PACKED>(r[j], st, lds, du[j]);
+            st[r[j].h.x] = (unsigned char)val;
+            if constexpr (COUNT) {
+                uint32_t *hp = reinterpret_cast<uint32_t *>(__builtin_assume_aligned(lds + r[j].h.y + val * 4u, 4));
+                __hip_atomic_fetch_add(hp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    for (uint32_t v = 0; v < p.n_vars; ++v) p.state[(size_t)v * p.pitch + chain] = st[v * kParStride];
+    if constexpr (COUNT) {
+        __syncthreads();
+        const uint32_t *h = reinterpret_cast<const uint32_t *>(lds + p.par_hist_off);
+        unsigned long long *gc = p.counts + (size_t)variant * p.H;
+        for (uint32_t i = tid; i < p.H; i += T) {
+            const uint32_t c = h[i];
+            if (c) atomicAdd(&gc[i], (unsigned long long)c);
+        }
+    }
+}
+
+template <int SLOTS, bool PACKED>
+static hipError_t launch_strict_t(const FastParams &p, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s) {
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, p);
+        return hipGetLastError();
+    };
+    return p.counting ? go(&k_sweep_strict<SLOTS, PACKED, true>) : go(&k_sweep_strict<SLOTS, PACKED, false>);
+}
+
+hipError_t launch_sweep_strict(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s) {
+    if (!packed && slots > 6) return hipErrorInvalidValue;
+    switch (slots) {
+    case 0: case 1: return packed ? launch_strict_t<1, true>(p, blocks, threads, lds, s) : launch_strict_t<1, false>(p, blocks, threads, lds, s);
+    case 2: return packed ? launch_strict_t<2, true>(p, blocks, threads, lds, s) : launch_strict_t<2, false>(p, blocks, threads, lds, s);
+    case 3: return packed ? launch_strict_t<3, true>(p, blocks, threads, lds, s) : launch_strict_t<3, false>(p, blocks, threads, lds, s);
+    case 4: return packed ? launch_strict_t<4, true>(p, blocks, threads, lds, s) : launch_strict_t<4, false>(p, blocks, threads, lds, s);
+    case 5: return packed ? launch_strict_t<5, true>(p, blocks, threads, lds, s) : launch_strict_t<5, false>(p, blocks, threads, lds, s);
+    case 6: return packed ? launch_strict_t<6, true>(p, blocks, threads, lds, s) : launch_strict_t<6, false>(p, blocks, threads, lds, s);
+    case 7: case 8: return launch_strict_t<8, true>(p, blocks, threads, lds, s);
+    case 9: case 10: case 11: case 12: return launch_strict_t<12, true>(p, blocks, threads, lds, s);
+    case 13: case 14: case 15: case 16: return launch_strict_t<16, true>(p, blocks, threads, lds, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+
 template <int SLOTS, bool PACKED>
 static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t lds, hipStream_t s) {
     auto go = [&](auto kern) -> hipError_t {

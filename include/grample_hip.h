@@ -104,7 +104,8 @@ int gr_error_suite(int32_t n_vars, const int32_t *card, const int32_t *fixed1, c
 #define GR_FLAG_CHAIN_PER_LANE (1u << 2) /* never use the step-parallel (4 lanes per chain) kernel */
 #define GR_FLAG_SCAN_PER_CHAIN (1u << 3) /* strict mode: every chain draws its own variable at every step, exactly like
                                             UniformSampler.VarSample per chain (sampler.go:135-174); the default shares the
-                                            draw inside a 64-chain group (same per-chain law).  Slow. */
+                                            draw inside a 64-chain group (same per-chain law).  About 2x slower on binary
+                                            memoised models (k_sweep_strict), 20x on the direct path. */
 
 typedef struct gr_sampler_opts {
     uint32_t struct_size;    /* = sizeof(gr_sampler_opts) */
@@ -185,7 +186,7 @@ typedef struct gr_sampler_info {
     uint32_t block_threads;
     uint32_t n_blocks;
     uint32_t lds_bytes;
-    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path), 3 = same, 4 lanes per chain */
+    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path), 3 = same, 4 lanes per chain, 5 = strict per-chain scan on memoised tables */
     uint32_t max_card;
     uint32_t tables_in_lds;
     uint32_t n_launches_last;

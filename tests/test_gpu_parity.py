@@ -194,6 +194,23 @@ def test_all_kernel_forms_agree_bit_for_bit(res_dir):
         assert np.array_equal(runs[0][2], runs[k][2]), k
 
 
+@pytest.mark.parametrize("name,chains,groups", [("Grids_13.uai", 2048, 1), ("Grids_13.uai", 66560, 1), ("Segmentation_11.uai", 1024, 4)])
+def test_strict_mode_memoised_equals_direct(res_dir, name, chains, groups):
+    """GR_FLAG_SCAN_PER_CHAIN (every chain draws its own variable, sampler.go:135-174): the memoised strict kernel
+    (path 5; one and four wavefronts per block; collapsed groups) and the generic kernel's strict mode (path 0)
+    are the same process bit for bit."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    out = []
+    for flags in (g.GR_FLAG_SCAN_PER_CHAIN, g.GR_FLAG_SCAN_PER_CHAIN | g.GR_FLAG_DIRECT):
+        s = g.HIPChains(m, chains, n_variants=groups, seed=17, flags=flags)
+        cv = [s.Collapse(k, -1)[0] for k in range(groups)] if groups > 1 else []
+        s.BurnIn(41); s.Advance(50); s.Advance(83)
+        out.append((s.info()["path"], cv, s.counts(), np.stack([s.LastSample(c) for c in (0, 63, chains // 2 + 5, chains - 1)])))
+    assert out[0][0] == 5 and out[1][0] == 0 and out[0][1] == out[1][1]
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+    assert int(out[0][2].sum()) == chains * 133
+
+
 # ------------------------------------------- 3. exact long-run law, tiny models
 @pytest.mark.parametrize("model", ["sample.uai", "grid3x3", "mixed", "mixed_evidence"])
 @pytest.mark.parametrize("flags", [0, g.GR_FLAG_DIRECT])
