@@ -202,6 +202,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res_dir)
             out["parity_probe"] = parity_probe(res_dir, g)
+            # the same workload with the reference's exact selection rule (every chain draws its own variable,
+            # sampler.go:135-174) instead of one draw per 64-chain group: a reported side figure
+            strict = g.HIPChains(model, CHAINS_PER_GPU, device=local_rank, seed=42, flags=g.GR_FLAG_SCAN_PER_CHAIN)
+            strict.BurnIn(BURNIN_SWEEPS * n_vars)
+            strict.Advance(upd_per_step)
+            out["strict_scan"] = {"value": CHAINS_PER_GPU * upd_per_step / (strict.info()["kernel_ms_last"] * 1e-3),
+                                  "unit": "variable-updates/s", "note": "GR_FLAG_SCAN_PER_CHAIN, kernel time of one step"}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -461,6 +461,12 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 const bool quad_blocks = act % 256u == 0 && act / 64u > 1024u && (o.n_variants == 1 || cpv % 256u == 0) &&
                                          par_lds + 3u * region <= kLdsBudget;
                 f.strict_state_off = par_lds;
+                {
+                    uint32_t nfree_max = 0;
+                    for (const auto &im : image) nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)im.free_vars.size());
+                    // the plan ring and Philox scratch areas behind the records are unused by this kernel
+                    f.strict_rec_stride = (uint64_t)nfree_max * (rec_stride + 16u) <= par_lds - par_rec_off ? rec_stride + 16u : rec_stride;
+                }
                 hip_check(launch_sweep_strict(f, fast_slots, par_packed, quad_blocks ? act / 256u : act / 64u, quad_blocks ? 256u : 64u,
                                               quad_blocks ? par_lds + 3u * region : par_lds, stream), "k_sweep_strict launch");
                 step += n; left -= n; launches_last++;

@@ -315,6 +315,26 @@ __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const
     return (u >= T) ? 1u : 0u;
 }
 
+// sample_l in two halves, so that independent work can be placed under the state reads' latency
+template <int SLOTS, bool PACKED>
+__device__ __forceinline__ void gather_l(const RecL<SLOTS, PACKED> &r, const unsigned char *lds_c, uint32_t (&x)[SLOTS]) {
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const uint32_t off = PACKED ? (comp4<SLOTS, PACKED>(r.s[i / 4], i % 4) & 0xffffu) : comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2));
+        x[i] = (uint32_t)lds_c[off];
+    }
+}
+template <int SLOTS, bool PACKED>
+__device__ __forceinline__ uint32_t table_l(const RecL<SLOTS, PACKED> &r, const uint32_t (&x)[SLOTS], const unsigned char *lds) {
+    uint32_t cfg4 = 0;
+#pragma unroll
+    for (int i = 0; i < SLOTS; ++i) {
+        const uint32_t m4 = PACKED ? (comp4<SLOTS, PACKED>(r.s[i / 4], i % 4) >> 16) : comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2) + 1);
+        cfg4 += __umul24(m4, x[i]);
+    }
+    return *reinterpret_cast<const uint32_t *>(lds + r.h.z + cfg4);
+}
+
 template <int SLOTS, bool PACKED, bool COUNT>
 __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -464,7 +484,8 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
         for (uint32_t i = tid; i < n4; i += T) dst[i] = src[i];
         const uint4 *rs = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.recs_par) + (size_t)vd.rec_base * p.rec_stride);
         uint4 *rd = reinterpret_cast<uint4 *>(lds + p.par_rec_off);
-        for (uint32_t i = tid; i < vd.n_free * (p.rec_stride / 16u); i += T) rd[i] = rs[i];
+        const uint32_t per = p.rec_stride / 16u, per_lds = p.strict_rec_stride / 16u; // records are padded in LDS, see below
+        for (uint32_t i = tid; i < vd.n_free * per; i += T) rd[(i / per) * per_lds + (i % per)] = rs[i];
         for (uint32_t v = 0; v < p.n_vars; ++v) st[v * kParStride] = p.state[(size_t)v * p.pitch + chain];
         uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
         for (uint32_t i = tid; i < p.H; i += T) h[i] = 0;
@@ -475,28 +496,44 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
     const uint64_t q0 = (((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2;
     const uint32_t nq = p.n_steps >> 2;
     const unsigned char *recs = lds + p.par_rec_off;
+    // The two Philox blocks of the NEXT quad (20 rounds) are computed in four slices, one under the state-read
+    // latency of each step of the current quad: a lone wavefront per SIMD has nothing else to hide it with.
+    u32x4 sc = philox4x32_10((uint32_t)q0, (uint32_t)(q0 >> 32), g_lo, DOM_SCAN_CHAIN + g_hi4, p.seed_lo, p.seed_hi);
+    u32x4 dr = philox4x32_10((uint32_t)q0, (uint32_t)(q0 >> 32), g_lo, DOM_DRAW + g_hi4, p.seed_lo, p.seed_hi);
     for (uint32_t qi = 0; qi < nq; ++qi) {
-        const uint64_t q = q0 + qi;
-        const u32x4 sc = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), g_lo, DOM_SCAN_CHAIN + g_hi4, p.seed_lo, p.seed_hi);
-        const u32x4 dr = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), g_lo, DOM_DRAW + g_hi4, p.seed_lo, p.seed_hi);
+        const uint64_t qn = q0 + qi + 1u;
         const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w}, du[4] = {dr.x, dr.y, dr.z, dr.w};
         RecL<SLOTS, PACKED> r[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) { // the records only depend on the scan stream: fetch all four first
-            const unsigned char *ra = recs + mul_hi_u32(su[j], vd.n_free) * p.rec_stride;
+            // per-lane record reads: with 64-byte strides every record would start in one of two bank groups; the
+            // LDS copy is padded to 80 (144) bytes so that the lanes' reads spread over all banks
+            const unsigned char *ra = recs + mul_hi_u32(su[j], vd.n_free) * p.strict_rec_stride;
             r[j].h = *reinterpret_cast<const uint4 *>(ra);
 #pragma unroll
             for (int i = 0; i < (int)(sizeof(r[j].s) / sizeof(uint4)); ++i) r[j].s[i] = *reinterpret_cast<const uint4 *>(ra + 16 + 16 * i);
         }
+        PhiloxSteps ps{(uint32_t)qn, (uint32_t)(qn >> 32), g_lo, DOM_SCAN_CHAIN + g_hi4, p.seed_lo, p.seed_hi};
+        PhiloxSteps pd{(uint32_t)qn, (uint32_t)(qn >> 32), g_lo, DOM_DRAW + g_hi4, p.seed_lo, p.seed_hi};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t val = sample_l<SLOTS, PACKED>(r[j], st, lds, du[j]);
+            uint32_t x[SLOTS];
+            gather_l<SLOTS, PACKED>(r[j], st, x);
+            __builtin_amdgcn_sched_barrier(0);
+            if (j == 0) ps.template rounds<5>();
+            else if (j == 1) pd.template rounds<5>();
+            else if (j == 2) ps.template rounds<5>();
+            else pd.template rounds<5>();
+            __builtin_amdgcn_sched_barrier(0);
+            const uint32_t val = (du[j] >= table_l<SLOTS, PACKED>(r[j], x, lds)) ? 1u : 0u;
             st[r[j].h.x] = (unsigned char)val;
             if constexpr (COUNT) {
                 uint32_t *hp = reinterpret_cast<uint32_t *>(__builtin_assume_aligned(lds + r[j].h.y + val * 4u, 4));
                 __hip_atomic_fetch_add(hp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
+        sc = u32x4{ps.c0, ps.c1, ps.c2, ps.c3};
+        dr = u32x4{pd.c0, pd.c1, pd.c2, pd.c3};
     }
     for (uint32_t v = 0; v < p.n_vars; ++v) p.state[(size_t)v * p.pitch + chain] = st[v * kParStride];
     if constexpr (COUNT) {

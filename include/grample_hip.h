@@ -104,7 +104,7 @@ int gr_error_suite(int32_t n_vars, const int32_t *card, const int32_t *fixed1, c
 #define GR_FLAG_CHAIN_PER_LANE (1u << 2) /* never use the step-parallel (4 lanes per chain) kernel */
 #define GR_FLAG_SCAN_PER_CHAIN (1u << 3) /* strict mode: every chain draws its own variable at every step, exactly like
                                             UniformSampler.VarSample per chain (sampler.go:135-174); the default shares the
-                                            draw inside a 64-chain group (same per-chain law).  About 2x slower on binary
+                                            draw inside a 64-chain group (same per-chain law).  About 1.6x slower on binary
                                             memoised models (k_sweep_strict), 20x on the direct path. */
 
 typedef struct gr_sampler_opts {
