@@ -116,6 +116,81 @@ def test_conditional_exhaustive_tiny(oracle):
         L.orc_simple_free(osamp); L.orc_gen_free(gen)
 
 
+def _random_model(rng):
+    """Random factor graph: cards 1..6, arity 1..5, zeros / 1e-6 / 1e-9 table entries (table epsilon rule, floored
+    conditionals), 0-30 % evidence.  Variable n-1 only ever gets a unary factor."""
+    from types import SimpleNamespace
+    n = int(rng.integers(3, 40))
+    card = [int(c) for c in rng.choice([1, 2, 2, 2, 3, 4, 5, 6], size=n)]
+    scopes, tables = [], []
+    for _ in range(int(rng.integers(n // 2, 3 * n))):
+        k = int(min(n, rng.integers(1, 6)))
+        sc = [int(v) for v in rng.choice(n - 1, size=min(k, n - 1), replace=False)]  # variable n-1 never gets a factor
+        size = int(np.prod([card[v] for v in sc]))
+        if size > 4096:
+            continue
+        t = np.exp(rng.uniform(-3, 3, size))
+        u = rng.random(size)
+        t[u < 0.10] = 0.0
+        t[(u >= 0.10) & (u < 0.14)] = 1e-6
+        t[(u >= 0.14) & (u < 0.17)] = 1e-9
+        scopes.append(sc); tables.append(t)
+    covered = {v for sc in scopes for v in sc}
+    for v in range(n):  # a variable in no factor is an error in the reference (gibbs-simple.go:96-99), tested separately
+        if v not in covered:
+            scopes.append([v]); tables.append(np.exp(rng.uniform(-1, 1, card[v])))
+    fixed = [int(rng.integers(0, c)) if rng.random() < rng.choice([0.0, 0.1, 0.3]) else -1 for c in card]
+    if all(f >= 0 for f in fixed):
+        fixed[0] = -1
+    return SimpleNamespace(card=card, scopes=scopes, tables=tables, fixed=fixed)
+
+
+def test_random_models_conditional_and_replay_vs_oracle(oracle):
+    """N4 generality: 30 random models through whatever kernel path the library picks -- device conditionals vs the
+    oracle's (same tolerance as the fixtures), and for the first 10 a bitwise replay by the numpy emulator."""
+    rng = np.random.default_rng(2024)
+    L = oracle.lib()
+    paths = set()
+    from types import SimpleNamespace
+    lonely = SimpleNamespace(card=[2, 2, 3], scopes=[[0, 1]], tables=[np.ones(4)], fixed=[-1, -1, -1])
+    gen = L.orc_gen_new(1)
+    assert not L.orc_simple_new(gen, oracle.Model.from_parsed(lonely).ptr)  # "There are no functions for var" on both sides
+    L.orc_gen_free(gen)
+    with pytest.raises(g.GrError, match="no functions for var"):
+        g.HIPChains(_gm(lonely), 64)
+    for mi in range(30):
+        pm = _random_model(rng)
+        om = oracle.Model.from_parsed(pm)
+        gen = L.orc_gen_new(1)
+        osamp = L.orc_simple_new(gen, om.ptr)
+        assert osamp, oracle.err()
+        s = g.HIPChains(_gm(pm), 64, seed=mi)
+        paths.add(s.info()["path"])
+        free = [v for v in range(len(pm.card)) if pm.fixed[v] < 0]
+        knife = 0
+        for _ in range(40):
+            st = np.array([rng.integers(0, c) if f < 0 else f for c, f in zip(pm.card, pm.fixed)], dtype=np.int32)
+            v = int(rng.choice(free))
+            pd = s.conditional(0, v, st)
+            po = _oracle_cond(oracle, osamp, v, st, pm.card[v])
+            bad = np.abs(pd - po) > COND_ABS + COND_REL * po
+            if bad.any():  # floor knife edge, see test_conditional_matches_oracle
+                edge = lambda p: np.minimum(np.abs(p / 1e-6 - 1.0), np.abs(p / 2e-6 - 1.0)) < 2e-4
+                assert np.all(edge(pd[bad]) & edge(po[bad])), (mi, v, pd, po)
+                knife += 1
+        assert knife <= 4, (mi, knife)
+        if mi < 10:
+            em = Emulator(pm.card, pm.fixed, free, _thresholds_from_device(s, pm.card), 64, mi)
+            assert np.array_equal(s.LastSample(63), em.state[:, 63])
+            s.BurnIn(5); em.run(5, False)
+            s.Advance(38); em.run(38, True)
+            assert np.array_equal(s.counts()[0], em.counts), mi
+            for c in (0, 31, 63):
+                assert np.array_equal(s.LastSample(c), em.state[:, c]), mi
+        L.orc_simple_free(osamp); L.orc_gen_free(gen)
+    assert len(paths) >= 2, paths  # the draw exercises more than one kernel path
+
+
 # --------------------------------------------------------- 2. process replay
 def _thresholds_from_device(s, cards):
     cache = {}
