@@ -51,6 +51,7 @@ struct SweepParams {
     // chains of the wavefront whose binary update drew 1; null = off
     unsigned char *log;
     uint32_t log_pitch, log_off;
+    uint32_t log_vals;          // bytes per logged step: 1 = the number of ones (all-binary models), else max Card (one count per value)
     uint32_t log_rows;          // rows per 64-chain group in the log (4 when the 4-lane form writes it); this kernel uses the first
 };
 
@@ -103,6 +104,8 @@ struct ScanArgs {
     uint32_t seed_lo, seed_hi;
     uint32_t n_vars;
     uint32_t step0_lo, step0_hi; // first step of the window
+    const uint32_t *hoff;        // [n_vars + 1] histogram offset of every variable (prefix sum of Card)
+    uint32_t H;
 };
 
 } // namespace gr

@@ -288,10 +288,18 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
                 if (lane == 0) {
                     hist[ho] += nact - ones;
                     hist[ho + 1] += ones;
-                    if (logrow) logrow[sidx] = (unsigned char)ones;
+                    if (logrow) {
+                        if (p.log_vals == 1) logrow[sidx] = (unsigned char)ones;
+                        else { logrow[sidx * p.log_vals] = (unsigned char)(nact - ones); logrow[sidx * p.log_vals + 1] = (unsigned char)ones; }
+                    }
                 }
-            } else if (active) {
-                atomicAdd(&hist[ho + val], 1u);
+            } else {
+                if (active) atomicAdd(&hist[ho + val], 1u);
+                if (!PC && logrow) // one count per value (log_vals = max Card)
+                    for (uint32_t c = 0; c < C; ++c) {
+                        const uint32_t n = (uint32_t)__popcll(__ballot(active && val == c));
+                        if (lane == 0) logrow[sidx * p.log_vals + c] = (unsigned char)n;
+                    }
             }
         }
     };
@@ -544,21 +552,24 @@ __global__ __launch_bounds__(64) void k_stop_time(const ScanArgs a, uint32_t cw,
 
 // ChainHistory's two halves (buffer/circular.go:54-84, chain.go:270-277), rebuilt from the draw log: walking the
 // window backwards, the newest `half` selections of a variable are its second half, the `half` before them its
-// first half.  ones[g][h][v] = number of chains that drew 1 in half h; status[g] = variables whose ring is not full.
+// first half.  hist[g][h][H] = how many chains drew each value in half h; status[g] = variables whose ring is not full.
+// The log holds per step either the number of ones (log_vals == 1, all-binary models, 64 chains per group) or one
+// count per value (log_vals = max Card).
 // One wavefront per group, 256 steps at a time: (0) every lane replays one quad of the scan stream and stages
-// (variable, ones) per step in LDS; (1) every lane lists, newest first, the steps whose variable it owns
+// (variable, counts) per step in LDS; (1) every lane lists, newest first, the steps whose variable it owns
 // (v mod 64 == lane); (2) the lanes walk their lists side by side -- a variable is only ever touched by its owner,
 // so the per-variable order of the serial walk is kept without atomics.
 __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch,
-                                                     uint32_t log_rows, uint32_t *ones /*[n_groups][2][n_vars]*/, uint32_t *status) {
+                                                     uint32_t log_rows, uint32_t log_vals, uint32_t *hist /*[n_groups][2][H]*/, uint32_t *status) {
     extern __shared__ uint32_t sm_scan[];
-    const uint32_t n = a.n_vars, g = blockIdx.x, lane = threadIdx.x;
-    uint32_t *sn = sm_scan, *o1 = sn + n, *o2 = o1 + n, *rem = o2 + n;
+    const uint32_t n = a.n_vars, H = a.H, g = blockIdx.x, lane = threadIdx.x;
+    uint32_t *sn = sm_scan, *o1 = sn + n, *o2 = o1 + H, *rem = o2 + H;
     unsigned short *cv = reinterpret_cast<unsigned short *>(rem + 1);
-    unsigned short *cl = cv + 256;
-    unsigned char *list = reinterpret_cast<unsigned char *>(cl + 256) + lane * 256u;
+    unsigned char *list = reinterpret_cast<unsigned char *>(cv + 256) + lane * 256u;
+    unsigned char *cl = reinterpret_cast<unsigned char *>(cv + 256) + 64u * 256u; // [256][log_vals]
     const ScanReplay sr(a, g);
-    for (uint32_t v = lane; v < n; v += 64u) { sn[v] = 0; o1[v] = 0; o2[v] = 0; }
+    for (uint32_t v = lane; v < n; v += 64u) sn[v] = 0;
+    for (uint32_t i = lane; i < H; i += 64u) { o1[i] = 0; o2[i] = 0; }
     if (lane == 0) *rem = sr.n_free;
     __syncthreads();
     const int64_t step0 = (int64_t)(((uint64_t)a.step0_hi << 32) | a.step0_lo);
@@ -574,10 +585,12 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
             for (uint32_t j = 0; j < 4; ++j) {
                 const int64_t k = q * 4 + j - step0;
                 const bool valid = k >= 0 && k < e;
-                uint32_t n1 = 0;
-                if (valid) for (uint32_t r = 0; r < log_rows; ++r) n1 += lg[(size_t)r * log_pitch + (size_t)k];
                 cv[lane * 4u + j] = valid ? (unsigned short)v[j] : (unsigned short)0xffffu;
-                cl[lane * 4u + j] = (unsigned short)n1;
+                for (uint32_t c = 0; c < log_vals; ++c) {
+                    uint32_t n1 = 0;
+                    if (valid) for (uint32_t r = 0; r < log_rows; ++r) n1 += lg[(size_t)r * log_pitch + (size_t)k * log_vals + c];
+                    cl[(lane * 4u + j) * log_vals + c] = (unsigned char)n1;
+                }
             }
         }
         __syncthreads();
@@ -594,7 +607,9 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
             if (k < mine) {
                 const uint32_t idx = list[k], v = cv[idx], c = sn[v];
                 if (c < 2u * half) {
-                    if (c < half) o2[v] += cl[idx]; else o1[v] += cl[idx];
+                    uint32_t *o = (c < half ? o2 : o1) + a.hoff[v];
+                    if (log_vals == 1) { o[1] += cl[idx]; o[0] += 64u - cl[idx]; }
+                    else for (uint32_t x = 0; x < a.hoff[v + 1] - a.hoff[v]; ++x) o[x] += cl[idx * log_vals + x];
                     sn[v] = c + 1u;
                     full += (c + 1u == 2u * half) ? 1u : 0u;
                 }
@@ -605,9 +620,9 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
         e = qlo * 4 - step0; // everything from quad qlo on is done
     }
     __syncthreads();
-    for (uint32_t v = lane; v < n; v += 64u) {
-        ones[((size_t)g * 2u + 0u) * n + v] = o1[v];
-        ones[((size_t)g * 2u + 1u) * n + v] = o2[v];
+    for (uint32_t i = lane; i < H; i += 64u) {
+        hist[((size_t)g * 2u + 0u) * H + i] = o1[i];
+        hist[((size_t)g * 2u + 1u) * H + i] = o2[i];
     }
     if (lane == 0) status[g] = half ? *rem : 0u;
 }
@@ -682,9 +697,11 @@ hipError_t launch_stop_time(const ScanArgs &a, uint32_t cw, uint32_t batch, uint
 }
 
 hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
-                              uint32_t *ones, uint32_t *status, hipStream_t s) {
-    const size_t lds = (3u * (size_t)a.n_vars + 1u) * sizeof(uint32_t) + 2u * 256u * sizeof(unsigned short) + 64u * 256u;
-    hipLaunchKernelGGL(k_ring_halves, dim3(a.n_groups), dim3(64), lds, s, a, n_steps, half, log, log_pitch, log_rows, ones, status);
+                              uint32_t log_vals, uint32_t *hist, uint32_t *status, hipStream_t s) {
+    const size_t lds = ((size_t)a.n_vars + 2u * a.H + 1u) * sizeof(uint32_t) + 256u * sizeof(unsigned short) + 64u * 256u + 256u * log_vals;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ring_halves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ring_halves, dim3(a.n_groups), dim3(64), lds, s, a, n_steps, half, log, log_pitch, log_rows, log_vals, hist, status);
     return hipGetLastError();
 }
 

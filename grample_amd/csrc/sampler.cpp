@@ -125,7 +125,7 @@ struct gr_sampler {
     Model base_linear;                           // the caller's model as given (linear tables): Adapt clones it
     // draw log of the current gr_advance_chain window (null = off)
     unsigned char *cur_log = nullptr;
-    uint32_t cur_log_pitch = 0, cur_log_rows = 1;
+    uint32_t cur_log_pitch = 0, cur_log_rows = 1, cur_log_vals = 1;
     uint64_t cur_log_step0 = 0;
     uint32_t active_chains() const { return o.n_variants > 1 ? n_active * (o.n_chains / o.n_variants) : o.n_chains; }
     double kernel_ms_last = 0;
@@ -409,7 +409,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
             p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
             p.n_steps = n;
-            p.log = cur_log; p.log_pitch = cur_log_pitch; p.log_rows = cur_log_rows; p.log_off = (uint32_t)(step - cur_log_step0);
+            p.log = cur_log; p.log_pitch = cur_log_pitch; p.log_rows = cur_log_rows; p.log_vals = cur_log_vals;
+            p.log_off = (uint32_t)(step - cur_log_step0) * cur_log_vals;
             // strict mode runs the direct arithmetic (bit-identical to the memoised tables); with strict_fast the LDS table
             // area holds thresholds, so the views are read from global memory
             hip_check(launch_sweep(p, max_card, cpt && !strict_fast, tab_lds && !strict_fast, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0,
@@ -1077,22 +1078,24 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
             worst = std::max(worst, b);
         }
         const uint64_t L = (uint64_t)worst * batch; // every group runs as long as the slowest one
-        // 2. run, logging every step's ones-count when all selectable variables are binary
+        // 2. run, logging every step's draws per group: the number of ones when all selectable variables are binary,
+        //    else one count per value (generic kernel only)
         bool binary = true;
         for (uint32_t g = 0; g < (s->o.n_variants > 1 ? s->n_active : 1u) && binary; ++g)
             for (uint32_t v : s->image[g].free_vars) binary = binary && s->card[v] == 2;
         const uint32_t rows = s->par ? 4u : 1u;
-        const uint64_t pitch = (L + 15u) & ~15ull;
-        const bool logging = binary && L <= 0xfffffff0ull && (uint64_t)n_groups * rows * pitch <= (16ull << 30);
+        const uint32_t log_vals = binary ? 1u : (uint32_t)s->max_card;
+        const uint64_t pitch = (L * log_vals + 15u) & ~15ull;
+        const bool logging = (binary || !s->fast) && pitch <= 0xfffffff0ull && (uint64_t)n_groups * rows * pitch <= (16ull << 30);
         const size_t nH = (size_t)s->o.n_variants * s->H;
         DevBuf<unsigned char> d_log;
         std::vector<uint64_t> c0(nH), c1(nH), c2(nH);
         if (logging) {
             d_log.alloc((size_t)n_groups * rows * pitch);
             hip_check(hipMemsetAsync(d_log.p, 0, (size_t)n_groups * rows * pitch, s->stream), "hipMemset");
-            s->cur_log = d_log.p; s->cur_log_pitch = (uint32_t)pitch; s->cur_log_rows = rows; s->cur_log_step0 = s->step;
+            s->cur_log = d_log.p; s->cur_log_pitch = (uint32_t)pitch; s->cur_log_rows = rows; s->cur_log_vals = log_vals; s->cur_log_step0 = s->step;
         }
-        struct Off { gr_sampler *s; ~Off() { s->cur_log = nullptr; s->cur_log_rows = 1; } } off{s};
+        struct Off { gr_sampler *s; ~Off() { s->cur_log = nullptr; s->cur_log_rows = 1; s->cur_log_vals = 1; } } off{s};
         if (logging) {
             s->run(L, true);
         } else { // no exact rings: fall back to the two halves of the window in time (gr_advance_window)
@@ -1110,25 +1113,25 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         if (logging) {
             // 3. rebuild every ring's halves: the last 2 * (cw / 2) selections of each variable (circular.go:16-28)
             const uint32_t half = cw / 2u;
-            DevBuf<uint32_t> d_ones, d_status;
-            d_ones.alloc((size_t)n_groups * 2u * s->n_vars);
+            DevBuf<uint32_t> d_hist, d_status, d_hoff;
+            std::vector<uint32_t> hoff(s->n_vars + 1, 0);
+            for (int v = 0; v < s->n_vars; ++v) hoff[v + 1] = hoff[v] + (uint32_t)s->card[v];
+            d_hoff.upload(hoff, s->stream);
+            a.hoff = d_hoff.p; a.H = (uint32_t)s->H;
+            d_hist.alloc((size_t)n_groups * 2u * s->H);
             d_status.alloc(n_groups);
-            hip_check(launch_ring_halves(a, (uint32_t)L, half, d_log.p, (uint32_t)pitch, rows, d_ones.p, d_status.p, s->stream), "k_ring_halves");
-            std::vector<uint32_t> ones((size_t)n_groups * 2u * s->n_vars), status(n_groups);
-            hip_check(hipMemcpyAsync(ones.data(), d_ones.p, ones.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
+            hip_check(launch_ring_halves(a, (uint32_t)L, half, d_log.p, (uint32_t)pitch, rows, log_vals, d_hist.p, d_status.p, s->stream), "k_ring_halves");
+            std::vector<uint32_t> hist((size_t)n_groups * 2u * s->H), status(n_groups);
+            hip_check(hipMemcpyAsync(hist.data(), d_hist.p, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
             hip_check(hipMemcpyAsync(status.data(), d_status.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
             s->sync();
             for (uint32_t st : status)
                 if (st) throw Error(GR_E_STATE, "a ChainHistory ring is not full after AdvanceChain (internal error)");
-            std::vector<uint32_t> hoff(s->n_vars, 0);
-            for (int v = 1; v < s->n_vars; ++v) hoff[v] = hoff[v - 1] + (uint32_t)s->card[v - 1];
             for (uint32_t g = 0; g < n_groups; ++g) {
                 const uint32_t variant = (g * 64u) / s->cpv;
-                for (uint32_t v : s->image[variant].free_vars) {
-                    const double n1 = ones[((size_t)g * 2u + 0u) * s->n_vars + v], n2 = ones[((size_t)g * 2u + 1u) * s->n_vars + v];
-                    const size_t o = (size_t)variant * s->H + hoff[v];
-                    s->win_first[o + 1] += n1;  s->win_first[o] += 64.0 * half - n1;
-                    s->win_second[o + 1] += n2; s->win_second[o] += 64.0 * half - n2;
+                for (int i = 0; i < s->H; ++i) {
+                    s->win_first[(size_t)variant * s->H + i] += hist[((size_t)g * 2u + 0u) * s->H + i];
+                    s->win_second[(size_t)variant * s->H + i] += hist[((size_t)g * 2u + 1u) * s->H + i];
                 }
             }
         } else {

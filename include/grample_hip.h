@@ -211,10 +211,10 @@ int gr_active_groups(gr_sampler *s);
 int gr_advance_window(gr_sampler *s, uint64_t updates_per_chain);
 /* Chain.AdvanceChain (chain.go:180-218) with its own stopping rule: batches of 2 N updates until every
  * selectable variable has been selected cw + 1 more times -- evaluated per 64-chain scan group from the
- * scan stream; every group then runs as long as the slowest one (out_updates, per chain).  For models
- * whose selectable variables are all binary the kernels log every step's draw count and the two halves
- * of every ChainHistory ring (the variable's last 2*(cw/2) selections, buffer/circular.go) are rebuilt
- * exactly for gr_adapt / ChainConvergence; otherwise the halves are those of the window in time. */
+ * scan stream; every group then runs as long as the slowest one (out_updates, per chain).  The kernels
+ * log every step's draws per group and the two halves of every ChainHistory ring (the variable's last
+ * 2*(cw/2) selections, buffer/circular.go) are rebuilt exactly for gr_adapt / ChainConvergence; a window
+ * whose log would exceed 16 GiB keeps the halves of the window in time instead. */
 int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_updates);
 /* the half-window histograms kept by the last gr_advance_window / gr_advance_chain:
  * first/second [n_variants * total_card] (inactive groups: zeros); *cw = the ConvergenceWindow they stand for */

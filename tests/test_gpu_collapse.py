@@ -333,13 +333,13 @@ def _expected_rings(em, n, cw, groups):
     for gi in range(groups):
         hist = {int(v): [] for v in free}
         for vs, vals in em.record:
-            hist[int(vs[gi * 64])].append(int(vals[gi * 64:(gi + 1) * 64].sum()))
-        for v, ones in hist.items():
-            ring = ones[-2 * half:]
+            v = int(vs[gi * 64])
+            hist[v].append(np.bincount(vals[gi * 64:(gi + 1) * 64], minlength=em.card[v]))
+        for v, sel in hist.items():
+            ring = sel[-2 * half:]
             assert len(ring) == 2 * half
             for dst, part in ((first, ring[:half]), (second, ring[half:])):
-                dst[em.hoff[v] + 1] += sum(part)
-                dst[em.hoff[v]] += 64 * half - sum(part)
+                dst[em.hoff[v]:em.hoff[v] + em.card[v]] += np.sum(part, axis=0)
     return batches * 2 * n, first, second
 
 
@@ -348,6 +348,8 @@ def _expected_rings(em, n, cw, groups):
     ("grid3x3", 7, 192, g.GR_FLAG_CHAIN_PER_LANE, 2),
     ("grid3x3", 6, 128, g.GR_FLAG_DIRECT, 0),
     ("Grids_11.uai", 2, 64, 0, 3),
+    ("mixed", 6, 128, 0, 1),            # cards 2, 3, 4: one logged count per value (memoised generic kernel)
+    ("mixed_evidence", 5, 64, g.GR_FLAG_DIRECT, 0),
 ])
 def test_advance_chain_stop_rule_and_rings_vs_emulator(res_dir, model, cw, chains, flags, path):
     from tests import exact_chain
@@ -404,12 +406,19 @@ def test_advance_chain_adaptive_flow_and_fallbacks(res_dir):
         sizes.append(s.active_groups())
     assert sizes == [5, 8, 8]
     assert int(s.counts().sum()) == s.TotalSampleCount()
-    # Card 16: no draw log -> halves in time, still the reference's stopping rule
+    # Card 16: one logged count per value; every variable's ring holds cw/2 selections x 128 chains in either half
     pm2 = uai_py.load(res_dir, "ObjectDetection_13.uai")
     s2 = g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, "ObjectDetection_13.uai")), 128, seed=5)
     L = s2.AdvanceChain(4)
     a, b, _ = s2.window_halves()
-    assert L % (2 * len(pm2.card)) == 0 and a.sum() + b.sum() == 128 * L
+    assert L % (2 * len(pm2.card)) == 0
+    for h in (a, b):
+        assert np.all(h[0].reshape(len(pm2.card), 16).sum(axis=1) == 128 * 2)
+    # a window too long to log (> 16 GiB): halves in time, still the reference's stopping rule
+    s3 = g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai")), 65536, seed=5)
+    L = s3.AdvanceChain(60000)
+    a, b, _ = s3.window_halves()
+    assert L * 4 * 1024 > (16 << 30) and a.sum() + b.sum() == 65536 * L
     with pytest.raises(g.GrError):
         g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai")), 64, flags=g.GR_FLAG_SCAN_PER_CHAIN).AdvanceChain(4)
     with pytest.raises(g.GrError):
