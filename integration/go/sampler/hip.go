@@ -171,4 +171,52 @@ func (c *HIPChains) Sample(s []int) (int, error) {
 	return idx, nil // idx == -1 when the update re-drew the same value
 }
 
+// NewHIPAdaptive = `--sampler adaptive` (cmd/root.go:408-415): room for maxChains chain groups
+// (reference MaxChains = 128, adaptive.go:49), baseCount of them running un-collapsed from the start.
+func NewHIPAdaptive(m *model.Model, chainsPerGroup, maxChains, baseCount, device int, seed int64, burnIn int64) (*HIPChains, error) {
+	gm, err := flatten(m)
+	if err != nil {
+		return nil, err
+	}
+	defer C.gr_model_destroy(gm)
+	o := C.gr_sampler_opts{
+		struct_size: C.uint32_t(unsafe.Sizeof(C.gr_sampler_opts{})),
+		n_chains: C.uint32_t(chainsPerGroup * maxChains), n_variants: C.uint32_t(maxChains),
+		device: C.int32_t(device), seed: C.uint64_t(seed),
+	}
+	h := C.gr_sampler_create(gm, &o)
+	if h == nil {
+		return nil, lastErr()
+	}
+	if C.gr_set_active_groups(h, C.uint32_t(baseCount)) != 0 {
+		return nil, lastErr()
+	}
+	if C.gr_burnin(h, C.uint64_t(burnIn)) != 0 {
+		return nil, errors.Wrap(lastErr(), "Failure during chain burn in")
+	}
+	return &HIPChains{h: h, base: m, nChains: chainsPerGroup * maxChains, variants: maxChains}, nil
+}
+
+// Adapt = ConvergenceSampler.Adapt (adaptive.go:57-157) after an AdvanceChain: merges the running
+// groups, ranks the candidates by ChainConvergence and starts up to newChainCount more groups, each
+// with one more collapsed variable. Returns the variables collapsed by the groups it added.
+func (c *HIPChains) Adapt(newChainCount int) ([]int, error) {
+	if newChainCount < 1 {
+		return nil, nil
+	}
+	vars := make([]C.int32_t, newChainCount)
+	var n C.uint32_t
+	if C.gr_adapt(c.h, C.uint32_t(newChainCount), &vars[0], &n, nil) != 0 {
+		return nil, errors.Wrap(lastErr(), "Could not adapt chains")
+	}
+	out := make([]int, int(n))
+	for i := range out {
+		out[i] = int(vars[i])
+	}
+	return out, nil
+}
+
+// ChainCount = len(chains) in cmd/root.go: the groups that currently run.
+func (c *HIPChains) ChainCount() int { return int(C.gr_active_groups(c.h)) }
+
 func (c *HIPChains) Close() { C.gr_sampler_destroy(c.h) }
