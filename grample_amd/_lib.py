@@ -83,6 +83,7 @@ SIGNATURES = {
     "gr_chain_convergence": (C.c_int, [i32, i32, pi32, pi32, pi32, pd, pd, pd, dbl, i32, pd]),
     "gr_adapt_select": (C.c_int, [vp, pi32, pd, u32, pi32, pu32]),
     "gr_adapt": (C.c_int, [vp, u32, pi32, pu32, pd]),
+    "gr_activate_group": (C.c_int, [vp, C.c_int32, C.POINTER(C.c_int32)]),
     "gr_philox4x32_10": (None, [pu32, pu32, pu32]),
 }
 

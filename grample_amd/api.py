@@ -271,6 +271,12 @@ class HIPChains:
         _chk(self.L.gr_adapt(self.ptr, newChainCount, _p(out, C.c_int32), C.byref(n), _p(conv, C.c_double)))
         return out[: n.value].tolist(), conv
 
+    def ActivateGroup(self, var=-1):
+        """The activation step of Adapt: next group <- fresh clone with `var` collapsed + burn-in of 2; returns the variable."""
+        out = C.c_int32(-1)
+        _chk(self.L.gr_activate_group(self.ptr, var, C.byref(out)))
+        return out.value
+
     def BurnIn(self, updates_per_chain):
         _chk(self.L.gr_burnin(self.ptr, updates_per_chain))
 

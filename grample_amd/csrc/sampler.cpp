@@ -1251,16 +1251,26 @@ GR_VISIBLE int gr_adapt(gr_sampler *s, uint32_t new_chain_count, int32_t *out_va
             if (gr_adapt_select(&base, coll.data(), conv.data(), slots, sel.data(), &n_sel)) throw Error(GR_E_INVALID, g_err);
         }
         for (uint32_t i = 0; i < n_sel; ++i) { // adaptive.go:131-153
-            const uint32_t g = s->n_active;
             int32_t cv = -1;
-            if (gr_collapse(s, g, sel[i], &cv, nullptr)) throw Error(GR_E_COLLAPSE, g_err);
-            s->n_active = g + 1;
-            s->counted_g[g] = 0;
-            // NewChain(..., burnIn = 2): two uncounted updates on the new group only, at step positions it has not used
-            if (s->dirty) s->rebuild();
-            s->burn_group(g, 2);
+            if (gr_activate_group(s, sel[i], &cv)) throw Error(GR_E_COLLAPSE, g_err);
             out_vars[(*out_n)++] = cv;
         }
+    });
+}
+
+GR_VISIBLE int gr_activate_group(gr_sampler *s, int32_t var_idx, int32_t *out_var) {
+    return guarded([&] {
+        if (!s) throw Error(GR_E_INVALID, "null sampler");
+        if (s->n_active >= s->o.n_variants) throw Error(GR_E_STATE, "every chain group is already active");
+        const uint32_t g = s->n_active;
+        int32_t cv = -1;
+        if (gr_collapse(s, g, var_idx, &cv, nullptr)) throw Error(GR_E_COLLAPSE, g_err);
+        s->n_active = g + 1;
+        s->counted_g[g] = 0;
+        // NewChain(..., burnIn = 2): two uncounted updates on the new group only, at step positions it has not used
+        if (s->dirty) s->rebuild();
+        s->burn_group(g, 2);
+        if (out_var) *out_var = cv;
     });
 }
 

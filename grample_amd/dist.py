@@ -51,3 +51,103 @@ def allreduce_counts(counts, group=None, device="cpu"):
     if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t.cpu().numpy().astype(np.uint64)
+
+
+# ---------------------------------------------------------------- Adapt over several devices / processes
+def adapt_plan(model, fixed, merged, collapsed, firsts, seconds, cw, actives, capacities, new_chain_count):
+    """ConvergenceSampler.Adapt's decisions (sampler/adaptive.go:57-157) for chain groups that live on several
+    samplers.  `merged` / `collapsed`: the MergeChains result over all of them; `firsts` / `seconds`: the
+    half-window histograms of every running group ([groups, H], any order); `actives` / `capacities`: running
+    groups and group slots per sampler.  Returns (list of (variable, sampler index), convergence scores or None):
+    every target goes to the sampler with the fewest running groups that still has a free slot (lowest index on
+    ties).  Pure host logic: identical inputs give identical plans on every rank."""
+    from . import api
+    actives, capacities = [int(a) for a in actives], [int(c) for c in capacities]
+    if sum(actives) < 2:
+        raise api.GrError("At least 2 chains required for adaptation")
+    slots = min(int(new_chain_count), sum(capacities) - sum(actives))
+    if slots <= 0:
+        return [], None  # MaxChains reached (adaptive.go:62-64)
+    conv = None
+    try:
+        targets = api.AdaptSelect(model, collapsed, None, slots)
+    except api.GrError:  # more candidates than slots: rank by ChainConvergence over the running groups
+        if firsts is None or len(firsts) == 0:
+            raise api.GrError("adapt needs a preceding AdvanceChain / AdvanceWindow")
+        conv = api.ChainConvergence(model.cards(), fixed, collapsed, firsts, seconds, merged, cw)
+        targets = api.AdaptSelect(model, collapsed, conv, slots)
+    plan, act = [], list(actives)
+    for var in targets:
+        free = [i for i in range(len(act)) if act[i] < capacities[i]]
+        owner = min(free, key=lambda i: (act[i], i))
+        act[owner] += 1
+        plan.append((int(var), owner))
+    return plan, conv
+
+
+def adapt_multi(samplers, model, new_chain_count):
+    """Adapt over several samplers of ONE process (one per device): merge, rank, activate.  Returns the plan."""
+    from . import api
+    merged, collapsed = api.MergeChains(samplers)
+    merged = np.concatenate(merged)
+    firsts, seconds, cw = [], [], 2.0
+    for s in samplers:
+        try:
+            a, b, cw = s.window_halves()
+        except api.GrError:
+            continue
+        n = s.active_groups()
+        firsts.append(a[:n]); seconds.append(b[:n])
+    firsts = np.concatenate(firsts) if firsts else None
+    seconds = np.concatenate(seconds) if seconds else None
+    plan, conv = adapt_plan(model, model.fixed(), merged, collapsed, firsts, seconds, cw,
+                            [s.active_groups() for s in samplers], [s.n_variants for s in samplers], new_chain_count)
+    for var, owner in plan:
+        samplers[owner].ActivateGroup(var)
+    return plan, conv
+
+
+def adapt_distributed(sampler, model, new_chain_count, group=None, device="cpu"):
+    """Adapt with one sampler per rank (torch.distributed; RCCL for "nccl", gloo in the CPU tests).  Exchanges: the
+    MergeChains all-reduces, one all-gather of (running groups, slots) and one of the half-window histograms.
+    `sampler` needs merge_local(), window_halves(), active_groups(), n_variants, ActivateGroup(var).
+    Every rank computes the same plan and activates its own share; returns (plan, scores)."""
+    cards = np.asarray(model.cards())
+    H = int(cards.sum())
+    s, cv, cm = sampler.merge_local()
+    merged, collapsed = allreduce_merge(s, cv, cm, cards, group=group, device=device)
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    rank = dist.get_rank(group) if on else 0
+    try:
+        a, b, cw = sampler.window_halves()
+        have = 1
+    except Exception:
+        a = b = np.zeros((sampler.n_variants, H)); cw, have = 2.0, 0
+    n_act = int(sampler.active_groups())
+    meta = torch.tensor([n_act, int(sampler.n_variants), have, int(round(cw * 4))], dtype=torch.int64, device=device)
+    metas = [torch.zeros_like(meta) for _ in range(world)]
+    if on:
+        dist.all_gather(metas, meta, group=group)
+    else:
+        metas = [meta]
+    metas = [m.cpu().numpy() for m in metas]
+    cap_max = int(max(m[1] for m in metas))
+    pack = np.zeros((2, cap_max, H))
+    pack[0, :n_act] = a[:n_act]; pack[1, :n_act] = b[:n_act]
+    t = torch.as_tensor(pack, device=device)
+    packs = [torch.zeros_like(t) for _ in range(world)]
+    if on:
+        dist.all_gather(packs, t, group=group)
+    else:
+        packs = [t]
+    firsts = np.concatenate([p.cpu().numpy()[0, : int(m[0])] for p, m in zip(packs, metas)])
+    seconds = np.concatenate([p.cpu().numpy()[1, : int(m[0])] for p, m in zip(packs, metas)])
+    if not all(int(m[2]) for m in metas):
+        firsts = seconds = None
+    plan, conv = adapt_plan(model, model.fixed(), merged, collapsed, firsts, seconds, max(int(m[3]) for m in metas) / 4.0,
+                            [int(m[0]) for m in metas], [int(m[1]) for m in metas], new_chain_count)
+    for var, owner in plan:
+        if owner == rank:
+            sampler.ActivateGroup(var)
+    return plan, conv

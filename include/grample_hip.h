@@ -237,6 +237,11 @@ int gr_adapt_select(const gr_model *base, const int32_t *merged_collapsed, const
  * NewChain with a burn-in of 2 updates (adaptive.go:131-153).  Nothing happens once all n_variants
  * groups are active.  out_converge [n_vars] may be NULL. */
 int gr_adapt(gr_sampler *s, uint32_t new_chain_count, int32_t *out_vars, uint32_t *out_n, double *out_converge);
+/* The activation step of Adapt alone (adaptive.go:131-153): the next inactive group gets a fresh clone of the
+ * base model with var_idx collapsed (-1 = random), a start state and NewChain's burn-in of 2 updates.  With
+ * gr_merge_local, gr_window_halves, gr_chain_convergence and gr_adapt_select this lets a host run Adapt over
+ * several devices or processes (grample_amd/dist.py: adapt_plan / adapt_distributed). */
+int gr_activate_group(gr_sampler *s, int32_t var_idx, int32_t *out_var);
 
 /* Philox4x32-10 block function on the host (same code the device runs);
  * exported so the known-answer vectors can be checked without a GPU. */

@@ -97,3 +97,97 @@ def test_single_process_is_identity():
     merged, flags = allreduce_merge(ls, cv, cm, CARDS)
     assert flags.tolist() == [1, 0, 0, 0]
     assert np.allclose(merged[2:], ls[2:]) and np.allclose(merged[:2], [0.3, 0.7])
+
+
+# ------------------------------------------------------------- Adapt over two ranks (N2 x multi-GPU)
+RES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "res")
+
+
+class _FakeSampler:
+    """What adapt_distributed needs from a sampler, fed with synthetic chain histories (no GPU)."""
+
+    def __init__(self, rank, cards, n_variants, n_active):
+        self.rank, self.cards, self.n_variants, self.n_active = rank, np.asarray(cards), n_variants, n_active
+        self.H = int(self.cards.sum())
+        self.activated = []
+
+    def active_groups(self):
+        return self.n_active
+
+    def _hist(self, group, half):
+        rng = np.random.default_rng(1000 * self.rank + 10 * group + half)
+        out = np.zeros(self.H)
+        off = 0
+        for c in self.cards:
+            p = rng.dirichlet(np.full(c, 1.0 + 4.0 * rng.random()))
+            out[off:off + c] = np.rint(p * 64 * 20)
+            off += c
+        return out
+
+    def window_halves(self):
+        a, b = np.zeros((self.n_variants, self.H)), np.zeros((self.n_variants, self.H))
+        for g in range(self.n_active):
+            a[g], b[g] = self._hist(g, 0), self._hist(g, 1)
+        return a, b, 40.0
+
+    def merge_local(self):
+        s = np.zeros(self.H)
+        off = 0
+        for c in self.cards:
+            s[off:off + c] += self.n_active * 64.0 / c
+            off += c
+        for g in range(self.n_active):
+            s += self._hist(g, 0) + self._hist(g, 1)
+        return s, np.full(len(self.cards), -1, dtype=np.int64), np.zeros(self.H)
+
+    def ActivateGroup(self, var):
+        self.activated.append(var)
+        self.n_active += 1
+        return var
+
+
+def _adapt_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import grample_amd as g
+    from grample_amd.dist import adapt_distributed
+    m = g.Model.NewModelFromFile(os.path.join(RES, "Segmentation_11.uai"))
+    fs = _FakeSampler(rank, m.cards(), 4 + rank, 1 + rank)  # rank 0: 1 of 4 groups running, rank 1: 2 of 5
+    plan, conv = adapt_distributed(fs, m, 3)
+    q.put((rank, plan, fs.activated, None if conv is None else conv.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world2_gloo_adapt_matches_single_process_plan():
+    """Both ranks compute the plan a single process computes from the union of the groups (adaptive.go:57-157),
+    targets go to the rank with the fewest running groups, and every rank activates exactly its share."""
+    import grample_amd as g
+    from grample_amd.dist import adapt_plan
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_adapt_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = g.Model.NewModelFromFile(os.path.join(RES, "Segmentation_11.uai"))
+    fakes = [_FakeSampler(0, m.cards(), 4, 1), _FakeSampler(1, m.cards(), 5, 2)]
+    merged = sum(f.merge_local()[0] for f in fakes)
+    firsts = np.concatenate([f.window_halves()[0][: f.n_active] for f in fakes])
+    seconds = np.concatenate([f.window_halves()[1][: f.n_active] for f in fakes])
+    exp_plan, exp_conv = adapt_plan(m, m.fixed(), merged, np.zeros(m.n_vars, dtype=np.int32), firsts, seconds, 40.0, [1, 2], [4, 5], 3)
+    assert len(exp_plan) == 3 and [o for _, o in exp_plan] == [0, 0, 1]  # 1|2 running -> 2|2 -> 3|2 -> 3|3
+    for rank, plan, activated, conv in res:
+        assert [tuple(x) for x in plan] == exp_plan
+        assert activated == [v for v, o in exp_plan if o == rank]
+        assert np.allclose(conv, exp_conv, rtol=1e-12, equal_nan=True)
+    # lowest scores are taken (adaptive.go:111-119 takes from the tail of the descending order)
+    picked = [v for v, _ in exp_plan]
+    elig = [v for v in range(m.n_vars) if not np.isnan(exp_conv[v])]
+    assert max(exp_conv[picked]) <= np.sort(exp_conv[elig])[len(picked) - 1] + 1e-15

@@ -423,3 +423,36 @@ def test_advance_chain_adaptive_flow_and_fallbacks(res_dir):
         g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai")), 64, flags=g.GR_FLAG_SCAN_PER_CHAIN).AdvanceChain(4)
     with pytest.raises(g.GrError):
         g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai")), 70).AdvanceChain(4)
+
+
+def test_adapt_over_two_samplers(res_dir):
+    """N2 x multi-GPU in one process: two samplers (here both on GPU 0; one per device in production) hold the chain
+    groups; adapt_multi merges them, ranks once and spreads the new groups; gr_activate_group does the collapse."""
+    from grample_amd.dist import adapt_multi
+    name = "Segmentation_11.uai"
+    pm = uai_py.load(res_dir, name)
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    n, cpv = len(pm.card), 64
+    a = g.HIPChains.NewGibbsCollapsed(gm, 4 * cpv, 4, seed=3)
+    b = g.HIPChains.NewGibbsCollapsed(gm, 4 * cpv, 4, seed=3, chain_offset=4 * cpv, variant_offset=4)
+    for s in (a, b):
+        s.set_active_groups(1)
+        s.BurnIn(3 * n)
+    added = []
+    for rnd in range(3):
+        for s in (a, b):
+            s.AdvanceChain(8)
+        plan, conv = adapt_multi([a, b], gm, 3)
+        added += plan
+    assert [a.active_groups(), b.active_groups()] == [4, 4]
+    assert [o for _, o in added] == [0, 1, 0, 1, 0, 1]  # always the sampler with fewer running groups
+    assert len({v for v, _ in added}) == 6
+    merged, coll = g.MergeChains([a, b])
+    assert sorted(np.where(coll)[0].tolist()) == sorted(v for v, _ in added)
+    with pytest.raises(g.GrError):
+        a.ActivateGroup(-1)  # no free group left
+    plan, _ = adapt_multi([a, b], gm, 3)
+    assert plan == []  # MaxChains reached: Adapt is the identity (adaptive.go:62-64)
+    off = np.concatenate([[0], np.cumsum(pm.card)])
+    for (v, o), k in zip(added, [1, 1, 2, 2, 3, 3]):
+        assert (a, b)[o].counts()[k, off[v]:off[v + 1]].sum() == 0  # the group never samples its collapsed variable
