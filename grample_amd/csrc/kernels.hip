@@ -202,7 +202,10 @@ __device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, 
 // UniformSampler.VarSample per chain (sampler.go:135-174); nothing is wave-uniform any more (divergent
 // program walks, per-lane histogram atomics).  Slow; exists so that the reference's exact process law is
 // available and the wave-uniform scan can be checked against it.
-template <int MAXC, bool CPT, bool TAB_LDS, bool PW, bool PC>
+// LOG: write the draw log of gr_advance_chain (only instantiated for the direct back-end, tables from global memory:
+// every back-end draws the same values, and keeping the log code out of the other instantiations keeps them compact --
+// with it inlined everywhere ObjectDetection_13 ran 17 % slower)
+template <int MAXC, bool CPT, bool TAB_LDS, bool PW, bool PC, bool LOG = false>
 __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t T = blockDim.x;
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     };
 
     // g.last[v] = val (gibbs-simple.go:267) and Marginal[val] += 1 (chain.go:230-236)
-    unsigned char *logrow = p.log ? p.log + (size_t)(chain >> 6) * p.log_rows * p.log_pitch + p.log_off : nullptr;
+    unsigned char *logrow = LOG && p.log ? p.log + (size_t)(chain >> 6) * p.log_rows * p.log_pitch + p.log_off : nullptr;
     auto commit = [&](const uint32_t v, const uint32_t *pg, const uint32_t val, const uint32_t sidx) {
         st[v * T] = (unsigned char)val;
         if (counting) {
@@ -288,14 +291,14 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
                 if (lane == 0) {
                     hist[ho] += nact - ones;
                     hist[ho + 1] += ones;
-                    if (logrow) {
+                    if (LOG && logrow) {
                         if (p.log_vals == 1) logrow[sidx] = (unsigned char)ones;
                         else { logrow[sidx * p.log_vals] = (unsigned char)(nact - ones); logrow[sidx * p.log_vals + 1] = (unsigned char)ones; }
                     }
                 }
             } else {
                 if (active) atomicAdd(&hist[ho + val], 1u);
-                if (!PC && logrow) // one count per value (log_vals = max Card)
+                if (LOG && !PC && logrow) // one count per value (log_vals = max Card)
                     for (uint32_t c = 0; c < C; ++c) {
                         const uint32_t n = (uint32_t)__popcll(__ballot(active && val == c));
                         if (lane == 0) logrow[sidx * p.log_vals + c] = (unsigned char)n;
@@ -638,12 +641,12 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
         else { constexpr int MC = 64; __VA_ARGS__; }               \
     } while (0)
 
-template <int MC, bool CPT, bool TL, bool PW, bool PC = false>
+template <int MC, bool CPT, bool TL, bool PW, bool PC = false, bool LOG = false>
 static hipError_t launch_sweep_t(const SweepParams &p, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<MC, CPT, TL, PW, PC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<MC, CPT, TL, PW, PC, LOG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sweep<MC, CPT, TL, PW, PC>), dim3(blocks), dim3(threads), lds, s, p);
+    hipLaunchKernelGGL((k_sweep<MC, CPT, TL, PW, PC, LOG>), dim3(blocks), dim3(threads), lds, s, p);
     return hipGetLastError();
 }
 
@@ -651,7 +654,8 @@ hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_l
                         uint32_t threads, uint32_t lds_bytes, hipStream_t s) {
     hipError_t e = hipSuccess;
     GR_DISPATCH_MAXC(max_card, {
-        if (per_chain) e = tab_lds ? launch_sweep_t<MC, false, true, false, true>(p, blocks, threads, lds_bytes, s)
+        if (p.log) e = (per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, false, true>(p, blocks, threads, lds_bytes, s);
+        else if (per_chain) e = tab_lds ? launch_sweep_t<MC, false, true, false, true>(p, blocks, threads, lds_bytes, s)
                                    : launch_sweep_t<MC, false, false, false, true>(p, blocks, threads, lds_bytes, s);
         else if (cpt) e = tab_lds ? launch_sweep_t<MC, true, true, false>(p, blocks, threads, lds_bytes, s)
                              : launch_sweep_t<MC, true, false, false>(p, blocks, threads, lds_bytes, s);

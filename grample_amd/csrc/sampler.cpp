@@ -413,7 +413,9 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             p.log_off = (uint32_t)(step - cur_log_step0) * cur_log_vals;
             // strict mode runs the direct arithmetic (bit-identical to the memoised tables); with strict_fast the LDS table
             // area holds thresholds, so the views are read from global memory
-            hip_check(launch_sweep(p, max_card, cpt && !strict_fast, tab_lds && !strict_fast, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0,
+            // ... and a logged window (gr_advance_chain) always runs the direct back-end, the only one built with the log code
+            const bool plain = strict_fast || cur_log != nullptr;
+            hip_check(launch_sweep(p, max_card, cpt && !plain, tab_lds && !plain, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0,
                                    (act + T - 1) / T, T, lds, stream), "k_sweep launch");
             step += n;
             left -= n;

@@ -20,6 +20,7 @@ CONFIGS = [
     ("configs[3] Segmentation_11 GibbsCollapsed 32768 chains, 128 groups", "Segmentation_11.uai", "collapsed", 32768, 128, 200, 1000, 65.7),
     ("configs[3'] Segmentation_11 adaptive 32768 chains, up to 128 groups", "Segmentation_11.uai", "adaptive", 32768, 128, 200, 1000, 65.7),
     ("configs[4] ObjectDetection_13 GibbsSimple, per-GPU share 32768 of 262144 chains", "ObjectDetection_13.uai", "simple", 32768, 1, 200, 600, 430.5),
+    ("configs[2'] Grids_13 65536 chains, strict per-chain variable selection (GR_FLAG_SCAN_PER_CHAIN)", "Grids_13.uai", "strict", 65536, 1, 200, 2000, 53.0),
 ]
 
 
@@ -27,7 +28,7 @@ def main():
     for title, model, samp, chains, groups, burn, sweeps, abytes in CONFIGS:
         m = g.Model.NewModelFromFile(os.path.join(RES, model))
         n = m.n_vars
-        s = g.HIPChains(m, chains, n_variants=groups, seed=42)
+        s = g.HIPChains(m, chains, n_variants=groups, seed=42, flags=g.GR_FLAG_SCAN_PER_CHAIN if samp == "strict" else 0)
         if samp == "collapsed":
             for k in range(groups):
                 s.Collapse(k, -1)
