@@ -154,27 +154,31 @@ __device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, 
     constexpr int NV = MAXC <= 2 ? 1 : MAXC / 4;
     const bool full = rowlen == (uint32_t)MAXC; // every row chunk is used: no per-chunk guards
     for (uint32_t f0 = 0; f0 < nf; f0 += GF) {
+        // Slots past the last factor re-read the last entry (clamped index) instead of being branched around: the GF
+        // entry loads, then the GF neighbour reads, then the GF x NV row loads are each issued back to back with one
+        // wait per stage.  (Guarding every slot made the compiler wait for each scalar entry load on its own -- a scalar
+        // cache round trip per factor with a lone wavefront per SIMD.)  Only the accumulation is guarded.
+        uint4 e[GF];
+#pragma unroll
+        for (int i = 0; i < GF; ++i) e[i] = ent[min(f0 + (uint32_t)i, nf - 1u)];
         const float *row[GF];
 #pragma unroll
-        for (int i = 0; i < GF; ++i)
-            if (f0 + i < nf) {
-                const uint4 e = ent[f0 + i];
-                conflict |= (e.y == p0) | (e.y == p1) | (e.y == p2);
-                row[i] = tab + (e.x + e.z * get(e.y));
-            }
+        for (int i = 0; i < GF; ++i) {
+            conflict |= (e[i].y == p0) | (e[i].y == p1) | (e[i].y == p2);
+            row[i] = tab + (e[i].x + e[i].z * get(e[i].y));
+        }
         float4 r[GF][NV];
 #pragma unroll
-        for (int i = 0; i < GF; ++i)
-            if (f0 + i < nf) {
-                if constexpr (MAXC <= 2) {
-                    const float2 t = *reinterpret_cast<const float2 *>(row[i]);
-                    r[i][0] = make_float4(t.x, t.y, 0.f, 0.f);
-                } else {
+        for (int i = 0; i < GF; ++i) {
+            if constexpr (MAXC <= 2) {
+                const float2 t = *reinterpret_cast<const float2 *>(row[i]);
+                r[i][0] = make_float4(t.x, t.y, 0.f, 0.f);
+            } else {
 #pragma unroll
-                    for (int c = 0; c < NV; ++c)
-                        if (full || (uint32_t)(4 * c) < rowlen) r[i][c] = *reinterpret_cast<const float4 *>(row[i] + 4 * c);
-                }
+                for (int c = 0; c < NV; ++c)
+                    if (full || (uint32_t)(4 * c) < rowlen) r[i][c] = *reinterpret_cast<const float4 *>(row[i] + 4 * c);
             }
+        }
 #pragma unroll
         for (int i = 0; i < GF; ++i)
             if (f0 + i < nf) {
