@@ -142,9 +142,9 @@ __device__ __forceinline__ void log_weights(const uint32_t *__restrict__ pg, con
 // consumed -- one table round trip per group instead of one per factor (the rows come from L2 when
 // the view tables do not fit LDS: ObjectDetection_13).  Accumulation stays in Model.Funcs order, so
 // the sums are bit-identical to log_weights().
-template <int MAXC, int GF, class Getter>
-__device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, const float *tab, Getter get, float (&w)[MAXC],
-                                               const uint32_t p0, const uint32_t p1, const uint32_t p2, bool &conflict) {
+template <int MAXC, int GF, bool FULLROW, class Getter>
+__device__ __forceinline__ void log_weights_pw_impl(const uint32_t *__restrict__ pg, const float *tab, Getter get, float (&w)[MAXC],
+                                                    const uint32_t p0, const uint32_t p1, const uint32_t p2, bool &conflict) {
     const uint32_t h = pg[0];
     const uint32_t rowlen = (h >> 8) & 0xffu;
     const uint32_t nf = h >> 16;
@@ -152,7 +152,6 @@ __device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, 
     for (int i = 0; i < MAXC; ++i) w[i] = 0.f;
     const uint4 *ent = reinterpret_cast<const uint4 *>(pg + 4);
     constexpr int NV = MAXC <= 2 ? 1 : MAXC / 4;
-    const bool full = rowlen == (uint32_t)MAXC; // every row chunk is used: no per-chunk guards
     for (uint32_t f0 = 0; f0 < nf; f0 += GF) {
         // Slots past the last factor re-read the last entry (clamped index) instead of being branched around: the GF
         // entry loads, then the GF neighbour reads, then the GF x NV row loads are each issued back to back with one
@@ -176,7 +175,7 @@ __device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, 
             } else {
 #pragma unroll
                 for (int c = 0; c < NV; ++c)
-                    if (full || (uint32_t)(4 * c) < rowlen) r[i][c] = *reinterpret_cast<const float4 *>(row[i] + 4 * c);
+                    if (FULLROW || (uint32_t)(4 * c) < rowlen) r[i][c] = *reinterpret_cast<const float4 *>(row[i] + 4 * c);
             }
         }
 #pragma unroll
@@ -188,12 +187,20 @@ __device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, 
                 } else {
 #pragma unroll
                     for (int c = 0; c < NV; ++c)
-                        if (full || (uint32_t)(4 * c) < rowlen) {
+                        if (FULLROW || (uint32_t)(4 * c) < rowlen) {
                             w[4 * c] += r[i][c].x; w[4 * c + 1] += r[i][c].y; w[4 * c + 2] += r[i][c].z; w[4 * c + 3] += r[i][c].w;
                         }
                 }
             }
     }
+}
+// FULLROW = the variable's rows use all MAXC values: one uniform test up front instead of a scalar guard per row
+// chunk and factor (those guards were most of the kernel's 313 scalar instructions per ObjectDetection_13 step).
+template <int MAXC, int GF, class Getter>
+__device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, const float *tab, Getter get, float (&w)[MAXC],
+                                               const uint32_t p0, const uint32_t p1, const uint32_t p2, bool &conflict) {
+    if (MAXC > 2 && ((pg[0] >> 8) & 0xffu) == (uint32_t)MAXC) log_weights_pw_impl<MAXC, GF, true>(pg, tab, get, w, p0, p1, p2, conflict);
+    else log_weights_pw_impl<MAXC, GF, false>(pg, tab, get, w, p0, p1, p2, conflict);
 }
 
 // ------------------------------------------------------------------- sweep
