@@ -135,8 +135,9 @@ __device__ __forceinline__ uint32_t sample_rec(const Rec &r, const unsigned char
 
 constexpr uint32_t kPlanChunk = 32; // quads per staged plan chunk (lanes 0..31 carry one quad each); the LDS ring holds two chunks per wave
 
-template <int SLOTS, bool PACKED, bool COUNT>
+template <int SLOTS, bool PACKED, int MODE> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
 __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
+    constexpr bool COUNT = MODE != 0, LOG = MODE == 2;
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t T = blockDim.x;
     const uint32_t tid = threadIdx.x;
@@ -192,7 +193,7 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
     }
     uint4 PV = ring_read(1); // plan of the NEXT quad, as uniform VGPRs
 
-    unsigned char *logrow = p.log ? p.log + (size_t)wave_local * p.log_pitch + p.log_off : nullptr;
+    unsigned char *logrow = LOG && p.log ? p.log + (size_t)wave_local * p.log_pitch + p.log_off : nullptr;
     auto commit = [&](const Rec &r, const uint32_t val, const uint32_t sidx) {
         st[r.w[0]] = (unsigned char)val;
         if constexpr (COUNT) {
@@ -200,7 +201,7 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
             if (lane < 2) {
                 uint32_t *hp = reinterpret_cast<uint32_t *>(lds + h_addr + r.w[1]);
                 __hip_atomic_fetch_add(hp, (uint32_t)(h_sign * (int)ones + h_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (logrow && lane == 1) logrow[sidx] = (unsigned char)ones;
+                if (LOG && logrow && lane == 1) logrow[sidx] = (unsigned char)ones;
             }
         }
     };
@@ -335,8 +336,9 @@ __device__ __forceinline__ uint32_t table_l(const RecL<SLOTS, PACKED> &r, const 
     return *reinterpret_cast<const uint32_t *>(lds + r.h.z + cfg4);
 }
 
-template <int SLOTS, bool PACKED, bool COUNT>
+template <int SLOTS, bool PACKED, int MODE> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
 __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
+    constexpr bool COUNT = MODE != 0, LOG = MODE == 2;
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // lane = step slot * 16 + chain: every 16-lane LDS lane group reads ONE record / plan word
@@ -384,7 +386,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
 
     // commit the step slots whose level equals `pass`: write the new values, count them.
     // The 16 chains of a step slot are one DPP row: row_shr 1,2,4,8 leave the number of ones in lane 15.
-    unsigned char *logrow = p.log ? p.log + (size_t)(blockIdx.x * 4u + wave) * p.log_pitch + p.log_off : nullptr;
+    unsigned char *logrow = LOG && p.log ? p.log + (size_t)(blockIdx.x * 4u + wave) * p.log_pitch + p.log_off : nullptr;
     auto commit = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine, const uint32_t sidx) {
         if (mine) lds[r.h.x + cb] = (unsigned char)val;
         if constexpr (COUNT) {
@@ -397,7 +399,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
                 uint32_t *hp = reinterpret_cast<uint32_t *>(__builtin_assume_aligned(lds + r.h.y, 4));
                 __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(hp + 1, (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (logrow) logrow[sidx] = (unsigned char)s1;
+                if (LOG && logrow) logrow[sidx] = (unsigned char)s1;
             }
         }
     };
@@ -582,7 +584,7 @@ static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t ld
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
         return hipGetLastError();
     };
-    return p.counting ? go(&k_sweep_par4<SLOTS, PACKED, true>) : go(&k_sweep_par4<SLOTS, PACKED, false>);
+    return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2>) : go(&k_sweep_par4<SLOTS, PACKED, 1>);
 }
 
 hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t lds, hipStream_t s) {
@@ -625,7 +627,7 @@ static hipError_t launch_bin_t(const FastParams &p, uint32_t blocks, uint32_t th
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, p);
         return hipGetLastError();
     };
-    return p.counting ? go(&k_sweep_bin<SLOTS, PACKED, true>) : go(&k_sweep_bin<SLOTS, PACKED, false>);
+    return !p.counting ? go(&k_sweep_bin<SLOTS, PACKED, 0>) : p.log ? go(&k_sweep_bin<SLOTS, PACKED, 2>) : go(&k_sweep_bin<SLOTS, PACKED, 1>);
 }
 
 hipError_t launch_scan_plan(const FastParams &p, hipStream_t s) {
