@@ -364,7 +364,7 @@ void gr_sampler::rebuild() {
         }
 
         const uint64_t waves = o.n_chains / 64u;
-        uint64_t ps = (64ull << 20) / (waves * 4ull); // <= 64 MiB of plan per launch
+        uint64_t ps = (256ull << 20) / (waves * 4ull); // <= 256 MiB of plan per launch
         ps = std::min<uint64_t>(ps, kMaxStepsPerLaunch) & ~15ull;
         plan_steps = (uint32_t)std::max<uint64_t>(ps, 16);
         d_plan.alloc((size_t)waves * plan_steps + 16);
