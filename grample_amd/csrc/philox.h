@@ -33,14 +33,24 @@ struct u32x4 {
     uint32_t x, y, z, w;
 };
 
+// a ^ b ^ c: one V_BITOP3_B32 on gfx950 (truth table 0x96) instead of two V_XOR_B32 -- the compiler does not form it
+// from the expression; a third of Philox's 60 vector instructions otherwise
+GR_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__) && __has_builtin(__builtin_amdgcn_bitop3_b32)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
+#else
+    return a ^ b ^ c;
+#endif
+}
+
 GR_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
         const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
         const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
         const uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += PHILOX_W0;

@@ -96,9 +96,9 @@ struct PhiloxSteps {
         for (int r = 0; r < N; ++r) {
             const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
             const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
-            const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+            const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
             const uint32_t n1 = (uint32_t)p1;
-            const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+            const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
             const uint32_t n3 = (uint32_t)p0;
             c0 = n0; c1 = n1; c2 = n2; c3 = n3;
             k0 += PHILOX_W0;
@@ -287,6 +287,15 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
 //   counts    DPP row reduction of the 16 draws of a step slot, then one lane adds (zeros, ones)
 constexpr uint32_t kParStride = 80;
 
+// LDS accesses by absolute LDS address.  The dynamic LDS array's base is a link-time symbol, so `lds + x` costs a
+// VALU add (of 0) at every use; the per-lane kernels stage their records with the base folded into the histogram and
+// table offsets and then address LDS by integer (the 4-lane form is VALU-issue-bound: 2 of ~28 instructions per step).
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+__device__ __forceinline__ uint32_t lds_addr_of(const void *p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p;
+}
+__device__ __forceinline__ lds_u32_t *lds_at(uint32_t addr) { return (lds_u32_t *)(uintptr_t)addr; }
+
 template <int SLOTS, bool PACKED>
 struct RecL { // a record as per-lane VGPR values
     uint4 h;                                 // state row offset, hist offset, table offset, nn
@@ -312,7 +321,7 @@ __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const
         }
         cfg4 += __umul24(m4, (uint32_t)lds_c[off]);
     }
-    const uint32_t T = *reinterpret_cast<const uint32_t *>(lds + r.h.z + cfg4);
+    const uint32_t T = *lds_at(r.h.z + cfg4); // r.h.z: absolute LDS address (staged records)
     return (u >= T) ? 1u : 0u;
 }
 
@@ -333,7 +342,7 @@ __device__ __forceinline__ uint32_t table_l(const RecL<SLOTS, PACKED> &r, const 
         const uint32_t m4 = PACKED ? (comp4<SLOTS, PACKED>(r.s[i / 4], i % 4) >> 16) : comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2) + 1);
         cfg4 += __umul24(m4, x[i]);
     }
-    return *reinterpret_cast<const uint32_t *>(lds + r.h.z + cfg4);
+    return *lds_at(r.h.z + cfg4); // r.h.z: absolute LDS address (staged records)
 }
 
 template <int SLOTS, bool PACKED, int MODE> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
@@ -355,7 +364,12 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         for (uint32_t i = tid; i < n4; i += 256) dst[i] = src[i];
         const uint4 *rs = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.recs_par) + (size_t)vd.rec_base * p.rec_stride);
         uint4 *rd = reinterpret_cast<uint4 *>(lds + p.par_rec_off);
-        for (uint32_t i = tid; i < vd.n_free * (p.rec_stride / 16u); i += 256) rd[i] = rs[i];
+        const uint32_t per = p.rec_stride / 16u, base = lds_addr_of(lds);
+        for (uint32_t i = tid; i < vd.n_free * per; i += 256) {
+            uint4 q = rs[i];
+            if (i % per == 0) { q.y += base; q.z += base; } // histogram and table offsets -> absolute LDS addresses
+            rd[i] = q;
+        }
         for (uint32_t v = j; v < p.n_vars; v += 4) lds[v * kParStride + cb] = p.state[(size_t)v * p.pitch + chain];
         uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
         for (uint32_t i = tid; i < p.H; i += 256) h[i] = 0;
@@ -396,7 +410,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             s1 += __builtin_amdgcn_update_dpp(0, s1, 0x114, 0xf, 0xf, true);
             s1 += __builtin_amdgcn_update_dpp(0, s1, 0x118, 0xf, 0xf, true);
             if (mine && tail) {
-                uint32_t *hp = reinterpret_cast<uint32_t *>(__builtin_assume_aligned(lds + r.h.y, 4));
+                lds_u32_t *hp = lds_at(r.h.y); // absolute LDS address (staged records)
                 __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(hp + 1, (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (LOG && logrow) logrow[sidx] = (unsigned char)s1;
@@ -487,7 +501,12 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
         const uint4 *rs = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.recs_par) + (size_t)vd.rec_base * p.rec_stride);
         uint4 *rd = reinterpret_cast<uint4 *>(lds + p.par_rec_off);
         const uint32_t per = p.rec_stride / 16u, per_lds = p.strict_rec_stride / 16u; // records are padded in LDS, see below
-        for (uint32_t i = tid; i < vd.n_free * per; i += T) rd[(i / per) * per_lds + (i % per)] = rs[i];
+        const uint32_t base = lds_addr_of(lds);
+        for (uint32_t i = tid; i < vd.n_free * per; i += T) {
+            uint4 q = rs[i];
+            if (i % per == 0) { q.y += base; q.z += base; } // histogram and table offsets -> absolute LDS addresses
+            rd[(i / per) * per_lds + (i % per)] = q;
+        }
         for (uint32_t v = 0; v < p.n_vars; ++v) st[v * kParStride] = p.state[(size_t)v * p.pitch + chain];
         uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
         for (uint32_t i = tid; i < p.H; i += T) h[i] = 0;
@@ -530,8 +549,7 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
             const uint32_t val = (du[j] >= table_l<SLOTS, PACKED>(r[j], x, lds)) ? 1u : 0u;
             st[r[j].h.x] = (unsigned char)val;
             if constexpr (COUNT) {
-                uint32_t *hp = reinterpret_cast<uint32_t *>(__builtin_assume_aligned(lds + r[j].h.y + val * 4u, 4));
-                __hip_atomic_fetch_add(hp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(lds_at(r[j].h.y + val * 4u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         sc = u32x4{ps.c0, ps.c1, ps.c2, ps.c3};
