@@ -345,7 +345,10 @@ __device__ __forceinline__ uint32_t table_l(const RecL<SLOTS, PACKED> &r, const 
     return *lds_at(r.h.z + cfg4); // r.h.z: absolute LDS address (staged records)
 }
 
-template <int SLOTS, bool PACKED, int MODE> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
+// HOIST: fetch the four records of an iteration together -- one LDS round trip instead of four.  Worth 7-12 % while a
+// SIMD holds fewer than ~3 wavefronts (latency-bound); with 4 per SIMD (65 536 chains) the VALU port is the limit and the
+// extra registers cost 1 %, so the launcher picks by occupancy.
+template <int SLOTS, bool PACKED, int MODE, bool HOIST_REQ> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
 __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     constexpr bool COUNT = MODE != 0, LOG = MODE == 2;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -437,13 +440,29 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             pw[k] = ring_w[((g0 + k) & (2u * kPlanChunk - 1u)) * 4u];
             U[k] = scr_r[k * 64];
         }
+        // the four records only depend on the plan: fetch them together (one LDS round trip instead of four)
+        constexpr bool HOIST = HOIST_REQ && SLOTS <= 8;
+        RecL<SLOTS, PACKED> rq[HOIST ? 4 : 1];
+        if constexpr (HOIST) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const unsigned char *ra = lds + rec_bias + (pw[k] & ~63u);
+                rq[k].h = *reinterpret_cast<const uint4 *>(ra);
+#pragma unroll
+                for (int i = 0; i < (int)(sizeof(rq[k].s) / sizeof(uint4)); ++i) rq[k].s[i] = *reinterpret_cast<const uint4 *>(ra + 16 + 16 * i);
+            }
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const unsigned char *ra = lds + rec_bias + (pw[k] & ~63u);
             RecL<SLOTS, PACKED> r;
-            r.h = *reinterpret_cast<const uint4 *>(ra);
+            if constexpr (HOIST) {
+                r = rq[k];
+            } else {
+                const unsigned char *ra = lds + rec_bias + (pw[k] & ~63u);
+                r.h = *reinterpret_cast<const uint4 *>(ra);
 #pragma unroll
-            for (int i = 0; i < (int)(sizeof(r.s) / sizeof(uint4)); ++i) r.s[i] = *reinterpret_cast<const uint4 *>(ra + 16 + 16 * i);
+                for (int i = 0; i < (int)(sizeof(r.s) / sizeof(uint4)); ++i) r.s[i] = *reinterpret_cast<const uint4 *>(ra + 16 + 16 * i);
+            }
             const uint32_t lv = (pw[k] >> 1) & 3u;
             const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
             const uint32_t sidx = (g0 + k) * 4u + j;
@@ -602,7 +621,10 @@ static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t ld
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
         return hipGetLastError();
     };
-    return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2>) : go(&k_sweep_par4<SLOTS, PACKED, 1>);
+    // fewer than 3 wavefronts per SIMD (256 CUs x 4 SIMDs, 4 wavefronts per block): latency-bound -> hoisted record reads
+    if (SLOTS <= 8 && blocks * 4u < 3u * 1024u)
+        return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, true>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, true>) : go(&k_sweep_par4<SLOTS, PACKED, 1, true>);
+    return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, false>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, false>) : go(&k_sweep_par4<SLOTS, PACKED, 1, false>);
 }
 
 hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t lds, hipStream_t s) {
