@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             U[k] = scr_r[k * 64];
         }
         // the four records only depend on the plan: fetch them together (one LDS round trip instead of four)
-        constexpr bool HOIST = HOIST_REQ && SLOTS <= 8;
+        constexpr bool HOIST = HOIST_REQ;
         RecL<SLOTS, PACKED> rq[HOIST ? 4 : 1];
         if constexpr (HOIST) {
 #pragma unroll
@@ -622,7 +622,7 @@ static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t ld
         return hipGetLastError();
     };
     // fewer than 3 wavefronts per SIMD (256 CUs x 4 SIMDs, 4 wavefronts per block): latency-bound -> hoisted record reads
-    if (SLOTS <= 8 && blocks * 4u < 3u * 1024u)
+    if (blocks * 4u < 3u * 1024u)
         return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, true>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, true>) : go(&k_sweep_par4<SLOTS, PACKED, 1, true>);
     return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, false>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, false>) : go(&k_sweep_par4<SLOTS, PACKED, 1, false>);
 }
