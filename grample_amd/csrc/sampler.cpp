@@ -442,6 +442,9 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.cpt = d_cpt.p; f.recs = d_recs.p; f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p;
         f.plan_pitch = plan_steps;
         f.rec_stride = rec_stride;
+        f.plan_slots = (uint32_t)std::max(fast_slots, 1);
+        f.plan_nfree_max = 1;
+        for (const auto &im : image) f.plan_nfree_max = std::max<uint32_t>(f.plan_nfree_max, (uint32_t)im.free_vars.size());
         f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = act; f.pitch = pitch; f.chains_per_variant = cpv;
         f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
         f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi;

@@ -31,34 +31,45 @@ namespace gr {
 
 __device__ __forceinline__ uint32_t uni_b(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
-// K0: scan plan.  One thread per (wavefront, quad of steps).
+// K0: scan plan.  One thread per (64-chain group, quad of steps); blockIdx.y = group.  The block first stages its
+// group's adjacency -- per selectable variable {id, neighbour count, neighbour ids} as u16 -- in LDS, so the
+// dependency tests below are LDS reads instead of chains of dependent global loads.
 __global__ void __launch_bounds__(256) k_scan_plan(const FastParams p) {
+    extern __shared__ unsigned short sp_tab[];
     const uint32_t nq = p.n_steps >> 2;
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_waves = p.n_chains >> 6;
-    if (idx >= n_waves * nq) return;
-    const uint32_t wave = idx / nq, qi = idx - wave * nq;
-    const uint64_t q = ((((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2) + qi;
-    const uint64_t gchain0 = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + (uint64_t)wave * 64u;
+    const uint32_t wave = blockIdx.y, qi = blockIdx.x * 256u + threadIdx.x;
     const uint32_t variant = (wave * 64u) / p.chains_per_variant;
     const VariantDesc vd = p.variants[variant];
+    const uint32_t S = 2u + p.plan_slots;
+    for (uint32_t k = threadIdx.x; k < vd.n_free; k += 256u) {
+        const uint32_t v = p.free_vars[vd.free_base + k];
+        const uint32_t *cp = p.cprogs + vd.cprog_base + p.cprog_off[vd.cprogoff_base + v];
+        const uint32_t nn = (cp[0] >> 8) & 0xffu;
+        sp_tab[k * S] = (unsigned short)v;
+        sp_tab[k * S + 1u] = (unsigned short)nn;
+        for (uint32_t i = 0; i < nn; ++i) sp_tab[k * S + 2u + i] = (unsigned short)cp[3 + 2 * i];
+    }
+    __syncthreads();
+    if (qi >= nq) return;
+    const uint64_t q = ((((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2) + qi;
+    const uint64_t gchain0 = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + (uint64_t)wave * 64u;
     const u32x4 sc = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)(gchain0 >> 6), DOM_SCAN, p.seed_lo, p.seed_hi);
     const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w};
     uint32_t k[4], v[4], out[4], level[4], maxlv = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         k[j] = mul_hi_u32(su[j], vd.n_free);
-        v[j] = p.free_vars[vd.free_base + k[j]];
+        const unsigned short *e = sp_tab + k[j] * S;
+        v[j] = e[0];
         // dependency level of step j inside its quad: 1 + the highest level of an earlier step that
         // updates the same variable or one of its neighbours (blankets are symmetric, so this also
         // covers "a later step overwrites what an earlier one still has to read").  Level 0 = commutes
         // with everything before it.
-        const uint32_t *cp = p.cprogs + vd.cprog_base + p.cprog_off[vd.cprogoff_base + v[j]];
-        const uint32_t nn = (cp[0] >> 8) & 0xffu;
+        const uint32_t nn = e[1];
         uint32_t lv = 0, adj_any = 0;
         for (int pj = 0; pj < j; ++pj) {
             uint32_t dep = (v[pj] == v[j]) ? 1u : 0u, adj = 0;
-            for (uint32_t i = 0; i < nn; ++i) adj |= (cp[3 + 2 * i] == v[pj]) ? 1u : 0u;
+            for (uint32_t i = 0; i < nn; ++i) adj |= (e[2 + i] == v[pj]) ? 1u : 0u;
             adj_any |= adj;
             if (dep | adj) lv = max(lv, level[pj] + 1u);
         }
@@ -671,9 +682,12 @@ static hipError_t launch_bin_t(const FastParams &p, uint32_t blocks, uint32_t th
 }
 
 hipError_t launch_scan_plan(const FastParams &p, hipStream_t s) {
-    const uint32_t n = (p.n_chains >> 6) * (p.n_steps >> 2);
-    if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_scan_plan, dim3((n + 255) / 256), dim3(256), 0, s, p);
+    const uint32_t n_waves = p.n_chains >> 6, nq = p.n_steps >> 2;
+    if (n_waves == 0 || nq == 0) return hipSuccess;
+    const size_t lds = (size_t)p.plan_nfree_max * (2u + p.plan_slots) * sizeof(unsigned short);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_scan_plan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_scan_plan, dim3((nq + 255u) / 256u, n_waves), dim3(256), lds, s, p);
     return hipGetLastError();
 }
 
