@@ -418,11 +418,11 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     auto commit = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine, const uint32_t sidx) {
         if (mine) lds[r.h.x + cb] = (unsigned char)val;
         if constexpr (COUNT) {
-            int s1 = (int)val;
-            s1 += __builtin_amdgcn_update_dpp(0, s1, 0x111, 0xf, 0xf, true);
-            s1 += __builtin_amdgcn_update_dpp(0, s1, 0x112, 0xf, 0xf, true);
-            s1 += __builtin_amdgcn_update_dpp(0, s1, 0x114, 0xf, 0xf, true);
-            s1 += __builtin_amdgcn_update_dpp(0, s1, 0x118, 0xf, 0xf, true);
+            // ones per step slot: prefix popcount of the draw mask (V_MBCNT), minus the prefix at the end of the previous
+            // DPP row (row_bcast:15) -- valid in lane 15 of every row, the lane that adds to the histogram
+            const unsigned long long drawn = __ballot(val != 0u);
+            const int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(drawn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)drawn, 0u)) + (int)val;
+            const int s1 = incl - __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xe, 0xf, false);
             if (mine && tail) {
                 lds_u32_t *hp = lds_at(r.h.y); // absolute LDS address (staged records)
                 __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
