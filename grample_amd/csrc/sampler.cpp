@@ -238,7 +238,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                 par = false;
                 const uint32_t form = try_strict_fast ? 2u : o.fast_form; // 0 auto, 1 chain per lane, 2 four lanes per chain
                 if (fast_ok && use_cpt && tl && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && form != 1 &&
-                    (form == 2 || o.n_chains / 64u <= 1536u || !cpl_fast)) {
+                    (form >= 2 || o.n_chains / 64u <= 1536u || !cpl_fast)) {
                     uint32_t nfree_max = 0;
                     for (const auto &im : image) nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)im.free_vars.size());
                     uint32_t b2 = ((uint32_t)n_vars * kParStateStride + 15u) & ~15u;
@@ -442,6 +442,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.cpt = d_cpt.p; f.recs = d_recs.p; f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p;
         f.plan_pitch = plan_steps;
         f.rec_stride = rec_stride;
+        f.par_recmode = o.fast_form >= 4 && o.fast_form <= 6 ? o.fast_form - 4u : 99u;
         f.plan_slots = (uint32_t)std::max(fast_slots, 1);
         f.plan_nfree_max = 1;
         for (const auto &im : image) f.plan_nfree_max = std::max<uint32_t>(f.plan_nfree_max, (uint32_t)im.free_vars.size());

@@ -359,7 +359,10 @@ __device__ __forceinline__ uint32_t table_l(const RecL<SLOTS, PACKED> &r, const 
 // HOIST: fetch the four records of an iteration together -- one LDS round trip instead of four.  Worth 7-12 % while a
 // SIMD holds fewer than ~3 wavefronts (latency-bound); with 4 per SIMD (65 536 chains) the VALU port is the limit and the
 // extra registers cost 1 %, so the launcher picks by occupancy.
-template <int SLOTS, bool PACKED, int MODE, bool HOIST_REQ> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
+// RECMODE 2: the records come from global memory instead (vector loads through L1, prefetched one iteration ahead):
+// the LDS pipe is this form's tightest resource and the record reads are 14 of its 48 cycles per step, while the
+// vector-memory path is otherwise idle.
+template <int SLOTS, bool PACKED, int MODE, int RECMODE> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
 __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     constexpr bool COUNT = MODE != 0, LOG = MODE == 2;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -379,11 +382,12 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         const uint4 *rs = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.recs_par) + (size_t)vd.rec_base * p.rec_stride);
         uint4 *rd = reinterpret_cast<uint4 *>(lds + p.par_rec_off);
         const uint32_t per = p.rec_stride / 16u, base = lds_addr_of(lds);
-        for (uint32_t i = tid; i < vd.n_free * per; i += 256) {
-            uint4 q = rs[i];
-            if (i % per == 0) { q.y += base; q.z += base; } // histogram and table offsets -> absolute LDS addresses
-            rd[i] = q;
-        }
+        if constexpr (RECMODE != 2)
+            for (uint32_t i = tid; i < vd.n_free * per; i += 256) {
+                uint4 q = rs[i];
+                if (i % per == 0) { q.y += base; q.z += base; } // histogram and table offsets -> absolute LDS addresses
+                rd[i] = q;
+            }
         for (uint32_t v = j; v < p.n_vars; v += 4) lds[v * kParStride + cb] = p.state[(size_t)v * p.pitch + chain];
         uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
         for (uint32_t i = tid; i < p.H; i += 256) h[i] = 0;
@@ -432,6 +436,24 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         }
     };
 
+    // RECMODE 2: records of the NEXT iteration, in flight while the current one runs
+    const unsigned char *recs_g = reinterpret_cast<const unsigned char *>(p.recs_par);
+    const uint32_t lbase = lds_addr_of(lds);
+    uint32_t pwn[4] = {0, 0, 0, 0};
+    RecL<SLOTS, PACKED> rn[RECMODE == 2 ? 4 : 1];
+    auto prefetch = [&](const uint32_t gnext) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t qd = min(gnext + (uint32_t)k, nq - 1u); // never past the plan: stale ring words are not offsets
+            pwn[k] = ring_w[(qd & (2u * kPlanChunk - 1u)) * 4u];
+            const unsigned char *ga = recs_g + (pwn[k] & ~63u);
+            rn[k].h = *reinterpret_cast<const uint4 *>(ga);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(rn[k].s) / sizeof(uint4)); ++i) rn[k].s[i] = *reinterpret_cast<const uint4 *>(ga + 16 + 16 * i);
+        }
+    };
+    if constexpr (RECMODE == 2) prefetch(0);
+
     for (uint32_t g0 = 0; g0 < nq; g0 += 4) {
         if ((g0 & (kPlanChunk - 1u)) == kPlanChunk / 2u) {
             const uint32_t nc = g0 / kPlanChunk + 1u;
@@ -446,15 +468,23 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
                                       DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
         *scr_w = make_uint4(W.x, W.y, W.z, W.w);
         uint32_t pw[4], U[4];
+        constexpr bool HOIST = RECMODE != 0;
+        RecL<SLOTS, PACKED> rq[HOIST ? 4 : 1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            pw[k] = ring_w[((g0 + k) & (2u * kPlanChunk - 1u)) * 4u];
+            if constexpr (RECMODE == 2) {
+                pw[k] = pwn[k];
+                rq[k] = rn[k];
+                rq[k].h.y += lbase; // offsets -> absolute LDS addresses (the LDS-staged records have them folded in)
+                rq[k].h.z += lbase;
+            } else {
+                pw[k] = ring_w[((g0 + k) & (2u * kPlanChunk - 1u)) * 4u];
+            }
             U[k] = scr_r[k * 64];
         }
-        // the four records only depend on the plan: fetch them together (one LDS round trip instead of four)
-        constexpr bool HOIST = HOIST_REQ;
-        RecL<SLOTS, PACKED> rq[HOIST ? 4 : 1];
-        if constexpr (HOIST) {
+        if constexpr (RECMODE == 2) prefetch(g0 + 4u);
+        // RECMODE 1: the four records only depend on the plan: fetch them together (one LDS round trip instead of four)
+        if constexpr (RECMODE == 1) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const unsigned char *ra = lds + rec_bias + (pw[k] & ~63u);
@@ -633,9 +663,13 @@ static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t ld
         return hipGetLastError();
     };
     // fewer than 3 wavefronts per SIMD (256 CUs x 4 SIMDs, 4 wavefronts per block): latency-bound -> hoisted record reads
-    if (blocks * 4u < 3u * 1024u)
-        return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, true>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, true>) : go(&k_sweep_par4<SLOTS, PACKED, 1, true>);
-    return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, false>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, false>) : go(&k_sweep_par4<SLOTS, PACKED, 1, false>);
+    // where the records come from (p.par_recmode: 0..2 forced, else by occupancy): with fewer than 3 wavefronts per SIMD
+    // (256 CUs x 4 SIMDs, 4 wavefronts per block) the kernel is latency-bound -> LDS records fetched together; with more it
+    // sits on the LDS pipe -> records from global memory, prefetched an iteration ahead
+    const int rm = p.par_recmode <= 2u ? (int)p.par_recmode : (blocks * 4u < 3u * 1024u ? 1 : 2);
+    if (rm == 2) return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 2>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 2>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 2>);
+    if (rm == 1) return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 1>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 1>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 1>);
+    return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 0>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 0>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 0>);
 }
 
 hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t lds, hipStream_t s) {

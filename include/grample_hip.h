@@ -117,7 +117,9 @@ typedef struct gr_sampler_opts {
     uint32_t variant_offset; /* global index of this device's variant 0 */
     uint32_t flags;          /* GR_FLAG_* */
     uint32_t block_threads;  /* 0 = auto; else 64/128/256 */
-    uint32_t fast_form;      /* tuning of the binary fast path: 0 = auto; 1 = chain per lane; 2 = 4 lanes per chain */
+    uint32_t fast_form;      /* tuning of the binary fast path: 0 = auto; 1 = chain per lane; 2 = 4 lanes per chain;
+                                4, 5, 6 = 4 lanes per chain with the step records read from LDS one by one / from LDS together /
+                                from global memory one iteration ahead (2 picks by occupancy) */
 } gr_sampler_opts;
 
 /* NewGibbsSimple for every chain (gibbs-simple.go:25-115): clones the model,
