@@ -409,8 +409,11 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         const uint32_t i = chunk * kPlanChunk + (lane & (kPlanChunk - 1u));
         return gplan[i < nq ? i : nq - 1];
     };
-    if (lane < kPlanChunk) ring[lane] = gload(0);
-    uint4 stage = gload(nchunks > 1 ? 1 : 0);
+    uint4 stage = make_uint4(0, 0, 0, 0);
+    if constexpr (RECMODE != 2) {
+        if (lane < kPlanChunk) ring[lane] = gload(0);
+        stage = gload(nchunks > 1 ? 1 : 0);
+    }
     uint32_t *scr = reinterpret_cast<uint32_t *>(lds + p.par_scr_off + wave * (64u * 16u));
     uint4 *scr_w = reinterpret_cast<uint4 *>(scr) + lane;  // my 4 words
     const uint32_t *scr_r = scr + (lane & 15u) * 4u + j;   // + k * 64: word j of lane (k, my chain)
@@ -441,21 +444,27 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     const uint32_t lbase = lds_addr_of(lds);
     uint32_t pwn[4] = {0, 0, 0, 0};
     RecL<SLOTS, PACKED> rn[RECMODE == 2 ? 4 : 1];
+    // ... and its plan words straight from global memory, two iterations ahead (no LDS ring in this mode)
+    const uint32_t *gplan_w = p.plan + (size_t)blockIdx.x * p.plan_pitch + j;
+    uint32_t pwa[4] = {0, 0, 0, 0};
+    auto prefetch_plan = [&](const uint32_t gnext) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pwa[k] = gplan_w[(size_t)min(gnext + (uint32_t)k, nq - 1u) * 4u]; // never past the plan
+    };
     auto prefetch = [&](const uint32_t gnext) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t qd = min(gnext + (uint32_t)k, nq - 1u); // never past the plan: stale ring words are not offsets
-            pwn[k] = ring_w[(qd & (2u * kPlanChunk - 1u)) * 4u];
+            pwn[k] = pwa[k];
             const unsigned char *ga = recs_g + (pwn[k] & ~63u);
             rn[k].h = *reinterpret_cast<const uint4 *>(ga);
 #pragma unroll
             for (int i = 0; i < (int)(sizeof(rn[k].s) / sizeof(uint4)); ++i) rn[k].s[i] = *reinterpret_cast<const uint4 *>(ga + 16 + 16 * i);
         }
     };
-    if constexpr (RECMODE == 2) prefetch(0);
+    if constexpr (RECMODE == 2) { prefetch_plan(0); prefetch(0); prefetch_plan(4); }
 
     for (uint32_t g0 = 0; g0 < nq; g0 += 4) {
-        if ((g0 & (kPlanChunk - 1u)) == kPlanChunk / 2u) {
+        if (RECMODE != 2 && (g0 & (kPlanChunk - 1u)) == kPlanChunk / 2u) {
             const uint32_t nc = g0 / kPlanChunk + 1u;
             if (nc < nchunks) {
                 if (lane < kPlanChunk) ring[(nc & 1u) * kPlanChunk + lane] = stage;
@@ -482,7 +491,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             }
             U[k] = scr_r[k * 64];
         }
-        if constexpr (RECMODE == 2) prefetch(g0 + 4u);
+        if constexpr (RECMODE == 2) { prefetch(g0 + 4u); prefetch_plan(g0 + 8u); }
         // RECMODE 1: the four records only depend on the plan: fetch them together (one LDS round trip instead of four)
         if constexpr (RECMODE == 1) {
 #pragma unroll
