@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
 //   state     lds[var * 80 + chain]           (80-byte rows: 4 different rows per access land on different banks)
 //   records   staged in LDS, read per lane (4 distinct records per access, broadcast inside a step slot)
 //   lanes     lane = j * 16 + c: a 16-lane LDS lane group / DPP row is one step slot
-//   draws     lane (j, c) computes Philox for quad 4*SQ + j of chain c; an LDS scratch transposes
+//   draws     lane (j, c) computes Philox for quad 4*SQ + j of chain c; two pairs of gfx950 lane swaps transpose
 //             the 4x4 words so that lane (j, c) ends up with word j of quads 4*SQ .. 4*SQ+3
 //   counts    DPP row reduction of the 16 draws of a step slot, then one lane adds (zeros, ones)
 constexpr uint32_t kParStride = 80;
@@ -414,9 +414,6 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         if (lane < kPlanChunk) ring[lane] = gload(0);
         stage = gload(nchunks > 1 ? 1 : 0);
     }
-    uint32_t *scr = reinterpret_cast<uint32_t *>(lds + p.par_scr_off + wave * (64u * 16u));
-    uint4 *scr_w = reinterpret_cast<uint4 *>(scr) + lane;  // my 4 words
-    const uint32_t *scr_r = scr + (lane & 15u) * 4u + j;   // + k * 64: word j of lane (k, my chain)
     const bool tail = (lane & 15u) == 15u;                 // holds the row sums after the DPP reduction
 
     // commit the step slots whose level equals `pass`: write the new values, count them.
@@ -475,8 +472,17 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         const uint64_t q = q0 + g0 + j;
         const u32x4 W = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain,
                                       DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
-        *scr_w = make_uint4(W.x, W.y, W.z, W.w);
+        // 4x4 transpose (step slots x words) with gfx950's lane swaps instead of an LDS round trip: V_PERMLANE32_SWAP
+        // exchanges the upper 32 lanes of one register with the lower 32 of another (slot bit 1 <-> word bit 1),
+        // V_PERMLANE16_SWAP the odd 16-lane rows with the even rows (slot bit 0 <-> word bit 0)
         uint32_t pw[4], U[4];
+        {
+            const auto a = __builtin_amdgcn_permlane32_swap(W.x, W.z, false, false);
+            const auto b = __builtin_amdgcn_permlane32_swap(W.y, W.w, false, false);
+            const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+            const auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+            U[0] = c[0]; U[1] = c[1]; U[2] = d[0]; U[3] = d[1];
+        }
         constexpr bool HOIST = RECMODE != 0;
         RecL<SLOTS, PACKED> rq[HOIST ? 4 : 1];
 #pragma unroll
@@ -489,7 +495,6 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             } else {
                 pw[k] = ring_w[((g0 + k) & (2u * kPlanChunk - 1u)) * 4u];
             }
-            U[k] = scr_r[k * 64];
         }
         if constexpr (RECMODE == 2) { prefetch(g0 + 4u); prefetch_plan(g0 + 8u); }
         // RECMODE 1: the four records only depend on the plan: fetch them together (one LDS round trip instead of four)
