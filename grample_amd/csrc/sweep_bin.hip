@@ -420,11 +420,12 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     // The 16 chains of a step slot are one DPP row: row_shr 1,2,4,8 leave the number of ones in lane 15.
     unsigned char *logrow = LOG && p.log ? p.log + (size_t)(blockIdx.x * 4u + wave) * p.log_pitch + p.log_off : nullptr;
     auto commit = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine, const uint32_t sidx) {
+        // the draw mask first: taken straight from the threshold compare while its result is still live
+        const unsigned long long drawn = COUNT ? __ballot(val != 0u) : 0ull;
         if (mine) lds[r.h.x + cb] = (unsigned char)val;
         if constexpr (COUNT) {
             // ones per step slot: prefix popcount of the draw mask (V_MBCNT), minus the prefix at the end of the previous
             // DPP row (row_bcast:15) -- valid in lane 15 of every row, the lane that adds to the histogram
-            const unsigned long long drawn = __ballot(val != 0u);
             const int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(drawn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)drawn, 0u)) + (int)val;
             const int s1 = incl - __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xe, 0xf, false);
             if (mine && tail) {
