@@ -9,7 +9,7 @@ import shutil
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-KERN = "k_sweep_par4<4, true, 1, false>"
+KERN = "k_sweep_par4<4, true, 1, 2>"
 
 
 def main():
