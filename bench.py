@@ -197,7 +197,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "note": f"algorithmic {ALGO_BYTES_PER_UPDATE} B/update x {per_launch_updates:.0f} updates/launch / "
                                  f"{per_launch_s * 1e3:.3f} ms mean launch (k_scan_plan + sweep kernel, HIP events on the sampler stream); "
-                                 "chain state + tables are LDS-resident, so real HBM traffic is far below the algorithmic bytes"},
+                                 "chain state + tables are LDS-resident, so real HBM traffic is far below the algorithmic bytes; "
+                                 "traffic = HBM bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this "
+                                 "command (profiles/hbm_traffic.json, gfx950 corrections applied)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(res_dir)
