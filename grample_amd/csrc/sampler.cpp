@@ -101,7 +101,7 @@ struct gr_sampler {
     bool fast = false;                // binary + memoised + whole wavefronts: sweep_bin.hip
     int fast_slots = 0;               // max neighbours of any selectable variable
     uint32_t plan_steps = 0;          // steps per fast launch (plan row length)
-    DevBuf<uint32_t> d_recs, d_plan, d_recs_par;
+    DevBuf<uint32_t> d_recs, d_plan, d_recs_par, d_err;
     bool par_packed = false;          // step-parallel records use one dword per neighbour
     uint32_t rec_stride = 64;         // bytes per record (128 when a variable has 13..16 neighbours)
     bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
@@ -443,6 +443,11 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.plan_pitch = plan_steps;
         f.rec_stride = rec_stride;
         f.par_recmode = o.fast_form >= 4 && o.fast_form <= 6 ? o.fast_form - 4u : 99u;
+        if (!d_err.p) {
+            d_err.alloc(1);
+            hip_check(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), stream), "hipMemset");
+        }
+        f.err = d_err.p;
         f.plan_slots = (uint32_t)std::max(fast_slots, 1);
         f.plan_nfree_max = 1;
         for (const auto &im : image) f.plan_nfree_max = std::max<uint32_t>(f.plan_nfree_max, (uint32_t)im.free_vars.size());
@@ -489,7 +494,10 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         if (left) generic_small(left);
     }
     hip_check(hipEventRecord(ev1, stream), "hipEventRecord");
+    uint32_t dev_err = 0;
+    if (d_err.p) hip_check(hipMemcpyAsync(&dev_err, d_err.p, sizeof dev_err, hipMemcpyDeviceToHost, stream), "D2H");
     sync();
+    if (dev_err) throw Error(GR_E_STATE, "device kernel refused to run: its LDS layout assumption does not hold (internal error)");
     float ms = 0;
     hip_check(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
     kernel_ms_last = ms;

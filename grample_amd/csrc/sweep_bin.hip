@@ -439,7 +439,14 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
 
     // RECMODE 2: records of the NEXT iteration, in flight while the current one runs
     const unsigned char *recs_g = reinterpret_cast<const unsigned char *>(p.recs_par);
-    const uint32_t lbase = lds_addr_of(lds);
+    // The global records hold offsets into the dynamic LDS array.  It starts at LDS address 0 because this kernel has no
+    // static LDS (the dynamic array follows the static segment), so the offsets are used as absolute addresses without
+    // two adds per step; should that ever change, fail loudly (error flag -> GR_E_STATE) instead of sampling from the
+    // wrong table.
+    if (RECMODE == 2 && lds_addr_of(lds) != 0u) { // every wave leaves at once; the host turns the flag into an error
+        if (threadIdx.x == 0) atomicOr(p.err, 1u);
+        return;
+    }
     uint32_t pwn[4] = {0, 0, 0, 0};
     RecL<SLOTS, PACKED> rn[RECMODE == 2 ? 4 : 1];
     // ... and its plan words straight from global memory, two iterations ahead (no LDS ring in this mode)
@@ -491,8 +498,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             if constexpr (RECMODE == 2) {
                 pw[k] = pwn[k];
                 rq[k] = rn[k];
-                rq[k].h.y += lbase; // offsets -> absolute LDS addresses (the LDS-staged records have them folded in)
-                rq[k].h.z += lbase;
+                // the offsets in the global records are absolute LDS addresses as they are: see the base check above
             } else {
                 pw[k] = ring_w[((g0 + k) & (2u * kPlanChunk - 1u)) * 4u];
             }
