@@ -419,16 +419,18 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     // commit the step slots whose level equals `pass`: write the new values, count them.
     // The 16 chains of a step slot are one DPP row: row_shr 1,2,4,8 leave the number of ones in lane 15.
     unsigned char *logrow = LOG && p.log ? p.log + (size_t)(blockIdx.x * 4u + wave) * p.log_pitch + p.log_off : nullptr;
-    auto commit = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine, const uint32_t sidx) {
-        // the draw mask first: taken straight from the threshold compare while its result is still live
-        const unsigned long long drawn = COUNT ? __ballot(val != 0u) : 0ull;
+    // A step's value is written at its own level's pass; the counting happens once per step slot after the last pass
+    // (histogram adds commute): ones per slot = prefix popcount of the draw mask (V_MBCNT) minus the prefix at the end of
+    // the previous DPP row (row_bcast:15) -- valid in lane 15 of every row, the lane that adds to the histogram.
+    auto store = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine) {
         if (mine) lds[r.h.x + cb] = (unsigned char)val;
+    };
+    auto count = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const uint32_t sidx) {
         if constexpr (COUNT) {
-            // ones per step slot: prefix popcount of the draw mask (V_MBCNT), minus the prefix at the end of the previous
-            // DPP row (row_bcast:15) -- valid in lane 15 of every row, the lane that adds to the histogram
+            const unsigned long long drawn = __ballot(val != 0u);
             const int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(drawn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)drawn, 0u)) + (int)val;
             const int s1 = incl - __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xe, 0xf, false);
-            if (mine && tail) {
+            if (tail) {
                 lds_u32_t *hp = lds_at(r.h.y); // absolute LDS address (staged records)
                 __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(hp + 1, (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -529,19 +531,23 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
             const uint32_t sidx = (g0 + k) * 4u + j;
             uint32_t val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-            commit(r, val, lv == 0, sidx);
+            store(r, val, lv == 0);
             if (maxlv >= 1) { // the quad has steps that do not commute: re-gather after the lower levels committed
-                val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-                commit(r, val, lv == 1, sidx);
+                uint32_t v2 = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+                store(r, v2, lv == 1);
+                val = lv == 1 ? v2 : val;
                 if (maxlv >= 2) {
-                    val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-                    commit(r, val, lv == 2, sidx);
+                    v2 = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+                    store(r, v2, lv == 2);
+                    val = lv == 2 ? v2 : val;
                     if (maxlv >= 3) {
-                        val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-                        commit(r, val, lv == 3, sidx);
+                        v2 = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+                        store(r, v2, lv == 3);
+                        val = lv == 3 ? v2 : val;
                     }
                 }
             }
+            count(r, val, sidx);
         }
     }
 
