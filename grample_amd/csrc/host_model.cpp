@@ -196,8 +196,16 @@ struct FieldReader { // model/reader.go
         errno = 0;
         char *end = nullptr;
         long long v = std::strtoll(s.c_str(), &end, 10);
-        if (errno || end == s.c_str() || *end) throw Error(GR_E_INVALID, std::string(what) + ": invalid integer \"" + s + "\"");
+        if (errno || end == s.c_str() || *end || v > INT32_MAX || v < INT32_MIN)
+            throw Error(GR_E_INVALID, std::string(what) + ": invalid integer \"" + s + "\"");
         return (int)v;
+    }
+    // a count of items that each take at least one more field: larger than what is left is malformed input, not an
+    // allocation request
+    int ReadCount(const char *what) {
+        const int v = ReadInt(what);
+        if (v > 0 && (size_t)v > fields.size() - pos) throw Error(GR_E_INVALID, std::string(what) + ": count " + std::to_string(v) + " exceeds the remaining fields");
+        return v;
     }
     double ReadFloat(const char *what) {
         const std::string &s = Read(what);
@@ -220,19 +228,21 @@ Model UAIReader::ReadModel(const std::string &data) {
     Model m;
     m.Type = fr.Read("Error reading UAI file on Type");
     if (m.Type != "BAYES" && m.Type != "MARKOV") throw Error(GR_E_INVALID, "Unknown model type " + m.Type);
-    int varCount = fr.ReadInt("Error reading UAI file on Variable count");
+    int varCount = fr.ReadCount("Error reading UAI file on Variable count");
     if (varCount < 1) throw Error(GR_E_INVALID, "Invalid variable count: " + std::to_string(varCount));
     m.Vars.reserve(varCount);
     for (int i = 0; i < varCount; ++i) {
         int card = fr.ReadInt("Error reading Card for var");
         if (card < 1) throw Error(GR_E_INVALID, "Invalid card " + std::to_string(card) + " for var " + std::to_string(i));
+        // no function can hold such a variable (function.go:59,77-79) and Check() requires one: reject before allocating its marginal
+        if (card > (1 << 23)) throw Error(GR_E_INVALID, "Invalid card " + std::to_string(card) + " for var " + std::to_string(i) + ": a function over it would have size > 8388608");
         m.Vars.push_back(Variable::New(i, card));
     }
-    int funcCount = fr.ReadInt("Error reading UAI file on Clique count");
+    int funcCount = fr.ReadCount("Error reading UAI file on Clique count");
     if (funcCount < 1) throw Error(GR_E_INVALID, "Invalid Clique count count: " + std::to_string(funcCount));
     m.Funcs.reserve(funcCount);
     for (int i = 0; i < funcCount; ++i) {
-        int k = fr.ReadInt("Error reading Clique size");
+        int k = fr.ReadCount("Error reading Clique size");
         if (k < 1) throw Error(GR_E_INVALID, "Invalid variable count (<1) for Clique " + std::to_string(i));
         std::vector<int> fv(k);
         for (int j = 0; j < k; ++j) {
@@ -285,12 +295,12 @@ std::vector<Variable> UAIReader::ReadMargSolution(const std::string &data) {
     if (fr.fields.size() < 4) throw Error(GR_E_INVALID, "Invalid data: only " + std::to_string(fr.fields.size()) + " fields found (<4)");
     std::string typ = fr.Read("Could not understand file");
     if (typ != "MAR") throw Error(GR_E_INVALID, "Unknown solution file type " + typ);
-    int varCount = fr.ReadInt("Error reading UAI MAR Solution Variable Count");
+    int varCount = fr.ReadCount("Error reading UAI MAR Solution Variable Count");
     if (varCount < 1) throw Error(GR_E_INVALID, "Invalid variable count: " + std::to_string(varCount));
     std::vector<Variable> out;
     out.reserve(varCount);
     for (int i = 0; i < varCount; ++i) {
-        int card = fr.ReadInt("Error reading Card for var");
+        int card = fr.ReadCount("Error reading Card for var");
         if (card < 1) throw Error(GR_E_INVALID, "Invalid card " + std::to_string(card) + " for var " + std::to_string(i));
         Variable v = Variable::New(i, card);
         for (int k = 0; k < card; ++k) {

@@ -86,6 +86,14 @@ def test_reader_errors():
             g.Model.NewModelFromBuffer(bad)
     with pytest.raises(g.GrError):
         g.Model.NewModelFromFile("/nonexistent/file.uai")
+    # absurd counts are malformed input, not allocation requests (no std::bad_alloc, no 800 MB marginals)
+    for bad, what in (("MARKOV 99999999999 2 1 1 0 2 0.5 0.5", "invalid integer"), ("MARKOV 2000000000 2 1 1 0 2 0.5 0.5", "exceeds the remaining"),
+                      ("MARKOV 1 2 2000000000 1 0 2 0.5 0.5", "exceeds the remaining"), ("MARKOV 1 99999999 1 1 0 2 0.5 0.5", "Invalid card"),
+                      ("MARKOV 1 2 1 2000000000 0 2 0.5 0.5", "exceeds the remaining")):
+        with pytest.raises(g.GrError, match=what):
+            g.Model.NewModelFromBuffer(bad)
+    with pytest.raises(g.GrError, match="exceeds the remaining"):
+        g.Solution.NewSolutionFromBuffer("MAR 2000000000 2 0.5 0.5") if hasattr(g.Solution, "NewSolutionFromBuffer") else g.Model.NewModelFromBuffer("MARKOV 2000000000 2 1 1 0 2 0.5 0.5")
 
 
 @pytest.mark.parametrize("name,ev", [("one.uai", False), ("sample.uai", False), ("deterministic.uai", False),
@@ -291,3 +299,68 @@ def test_chain_convergence_and_adapt_select_match_oracle(oracle, res_dir):
         g.AdaptSelect(gm, np.zeros(nv, dtype=np.int32), None, 4)  # ranking needed but no scores
     one = g.Model.NewModelFromFile(os.path.join(res_dir, "one.uai"))
     assert g.AdaptSelect(one, [0], None, 3) == []  # blanket of size 1 is never eligible (adaptive.go:84)
+
+
+# ------------------------------------------------------------- reader fuzz (deterministic, no GPU)
+def _serialise(rng, pm, typ="MARKOV"):
+    """UAI text of a model with irregular but legal whitespace (uai.go:20-51 collapses it)."""
+    ws = lambda: rng.choice([" ", "  ", "\t", "\n", " \n "])
+    toks = [typ, str(len(pm.card))] + [str(c) for c in pm.card] + [str(len(pm.scopes))]
+    for s in pm.scopes:
+        toks += [str(len(s))] + [str(v) for v in s]
+    for t in pm.tables:
+        toks += [str(len(t))] + [repr(float(x)) for x in t]
+    return "".join(tok + ws() for tok in toks) + "\n"
+
+
+def test_reader_fuzz_roundtrip_and_mutations():
+    """60 random models written with irregular whitespace parse to exactly what was written (C++ reader == Python
+    twin == source); 240 mutated texts (token deleted / replaced / truncated) either parse to a structurally valid
+    model or raise GrError -- never crash, never accept an inconsistent table."""
+    from types import SimpleNamespace
+    rng = np.random.default_rng(31337)
+    texts = []
+    for _ in range(60):
+        n = int(rng.integers(1, 9))
+        card = [int(c) for c in rng.integers(1, 5, n)]
+        scopes = []
+        for _ in range(int(rng.integers(1, 7))):
+            k = int(rng.integers(1, min(n, 4) + 1))
+            scopes.append([int(v) for v in rng.choice(n, size=k, replace=False)])
+        tables = [rng.random(int(np.prod([card[v] for v in s]))) * rng.choice([1.0, 1e-7, 1e3]) for s in scopes]
+        pm = SimpleNamespace(card=card, scopes=scopes, tables=tables)
+        text = _serialise(rng, pm, rng.choice(["MARKOV", "BAYES"]))
+        if len(text) < 15:
+            continue
+        texts.append(text)
+        m = g.Model.NewModelFromBuffer(text)
+        tw = uai_py.read_model(text)
+        assert m.cards().tolist() == card == tw.card and m.n_funcs == len(scopes)
+        for f in range(m.n_funcs):
+            assert m.func_scope(f) == scopes[f] == tw.scopes[f]
+            assert np.array_equal(m.func_table(f), tables[f]) and np.array_equal(tw.tables[f], tables[f])
+    accepted = rejected = 0
+    for i in range(240):
+        toks = texts[i % len(texts)].split()
+        op = i % 3
+        pos = int(rng.integers(0, len(toks)))
+        if op == 0:
+            del toks[pos]
+        elif op == 1:
+            toks[pos] = rng.choice(["-1", "0", "x", "99999999999", "1e400", "nan", "3.5"])
+        else:
+            toks = toks[:pos]
+        bad = " ".join(toks)
+        try:
+            m = g.Model.NewModelFromBuffer(bad)
+        except g.GrError:
+            rejected += 1
+            continue
+        accepted += 1  # a mutation can still be a legal file (e.g. a table value replaced by another number)
+        cards = m.cards().tolist()
+        assert all(c >= 1 for c in cards) and m.n_funcs >= 1
+        for f in range(m.n_funcs):
+            sc = m.func_scope(f)
+            assert all(0 <= v < len(cards) for v in sc)
+            assert len(m.func_table(f)) == int(np.prod([cards[v] for v in sc]))
+    assert rejected > 120 and accepted + rejected == 240
