@@ -51,6 +51,10 @@ struct SweepParams {
     // chains of the wavefront whose binary update drew 1; null = off
     unsigned char *log;
     uint32_t log_pitch, log_off;
+    const uint32_t *limit;      // with the log: per 64-chain group, how many steps of the window it executes (its own AdvanceChain
+                                // stopping time); later steps of the window leave the group untouched.  win_off = steps of the
+                                // window before this launch
+    uint32_t win_off;
     uint32_t log_vals;          // bytes per logged step: 1 = the number of ones (all-binary models), else max Card (one count per value)
     uint32_t log_rows;          // rows per 64-chain group in the log (4 when the 4-lane form writes it); this kernel uses the first
 };
@@ -87,6 +91,7 @@ struct FastParams {
     // step-parallel form (k_sweep_par4): its own records (80-byte state rows) and LDS layout
     unsigned char *log;          // optional draw log, see SweepParams (4-lane form: one row per wavefront = 16 chains)
     uint32_t log_pitch, log_off;
+    const uint32_t *limit;       // see SweepParams::limit (window offset of the launch = log_off)
     const uint32_t *recs_par;
     uint32_t par_hist_off, par_tab_off, par_rec_off, par_plan_off, par_scr_off;
     uint32_t *err;               // device error word (bit 0: the dynamic LDS array does not start at LDS address 0)

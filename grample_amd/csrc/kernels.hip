@@ -293,7 +293,15 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
 
     // g.last[v] = val (gibbs-simple.go:267) and Marginal[val] += 1 (chain.go:230-236)
     unsigned char *logrow = LOG && p.log ? p.log + (size_t)(chain >> 6) * p.log_rows * p.log_pitch + p.log_off : nullptr;
+    // LOG: the group's own stopping time inside the window (steps of this launch it still executes)
+    uint32_t lim = 0xffffffffu;
+    if constexpr (LOG)
+        if (p.limit) {
+            const uint32_t t = p.limit[chain >> 6];
+            lim = t > p.win_off ? t - p.win_off : 0u;
+        }
     auto commit = [&](const uint32_t v, const uint32_t *pg, const uint32_t val, const uint32_t sidx) {
+        if (LOG && sidx >= lim) return; // the group has finished its AdvanceChain: state, counts and log stay as they are
         st[v * T] = (unsigned char)val;
         if (counting) {
             const uint32_t C = pg[0] & 0xffu, ho = pg[1];
@@ -574,7 +582,8 @@ __global__ __launch_bounds__(64) void k_stop_time(const ScanArgs a, uint32_t cw,
 // (v mod 64 == lane); (2) the lanes walk their lists side by side -- a variable is only ever touched by its owner,
 // so the per-variable order of the serial walk is kept without atomics.
 __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch,
-                                                     uint32_t log_rows, uint32_t log_vals, uint32_t *hist /*[n_groups][2][H]*/, uint32_t *status) {
+                                                     uint32_t log_rows, uint32_t log_vals, const uint32_t *limit /*[n_groups] or null*/, uint32_t *hist /*[n_groups][2][H]*/,
+                                                     uint32_t *status) {
     extern __shared__ uint32_t sm_scan[];
     const uint32_t n = a.n_vars, H = a.H, g = blockIdx.x, lane = threadIdx.x;
     uint32_t *sn = sm_scan, *o1 = sn + n, *o2 = o1 + H, *rem = o2 + H;
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
     __syncthreads();
     const int64_t step0 = (int64_t)(((uint64_t)a.step0_hi << 32) | a.step0_lo);
     const unsigned char *lg = log + (size_t)g * log_rows * log_pitch;
-    int64_t e = half ? (int64_t)n_steps : 0; // steps [0, e) of the window are still to be visited
+    int64_t e = half ? (int64_t)(limit ? limit[g] : n_steps) : 0; // steps [0, e) of the group's window are still to be visited
     while (e > 0 && *rem) {
         const int64_t qhi = (step0 + e - 1) >> 2, qlo = qhi - 63;
         { // (0) stage the chunk
@@ -712,11 +721,11 @@ hipError_t launch_stop_time(const ScanArgs &a, uint32_t cw, uint32_t batch, uint
 }
 
 hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
-                              uint32_t log_vals, uint32_t *hist, uint32_t *status, hipStream_t s) {
+                              uint32_t log_vals, const uint32_t *limit, uint32_t *hist, uint32_t *status, hipStream_t s) {
     const size_t lds = ((size_t)a.n_vars + 2u * a.H + 1u) * sizeof(uint32_t) + 256u * sizeof(unsigned short) + 64u * 256u + 256u * log_vals;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ring_halves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ring_halves, dim3(a.n_groups), dim3(64), lds, s, a, n_steps, half, log, log_pitch, log_rows, log_vals, hist, status);
+    hipLaunchKernelGGL(k_ring_halves, dim3(a.n_groups), dim3(64), lds, s, a, n_steps, half, log, log_pitch, log_rows, log_vals, limit, hist, status);
     return hipGetLastError();
 }
 

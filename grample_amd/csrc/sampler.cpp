@@ -126,6 +126,8 @@ struct gr_sampler {
     // draw log of the current gr_advance_chain window (null = off)
     unsigned char *cur_log = nullptr;
     uint32_t cur_log_pitch = 0, cur_log_rows = 1, cur_log_vals = 1;
+    const uint32_t *cur_limit = nullptr;  // per scan group: steps of the window it executes (gr_advance_chain)
+    uint64_t skipped_updates = 0;         // updates NOT made inside such windows by groups that stopped before the slowest one
     uint64_t cur_log_step0 = 0;
     uint32_t active_chains() const { return o.n_variants > 1 ? n_active * (o.n_chains / o.n_variants) : o.n_chains; }
     double kernel_ms_last = 0;
@@ -411,6 +413,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             p.n_steps = n;
             p.log = cur_log; p.log_pitch = cur_log_pitch; p.log_rows = cur_log_rows; p.log_vals = cur_log_vals;
             p.log_off = (uint32_t)(step - cur_log_step0) * cur_log_vals;
+            p.limit = cur_limit; p.win_off = (uint32_t)(step - cur_log_step0);
             // strict mode runs the direct arithmetic (bit-identical to the memoised tables); with strict_fast the LDS table
             // area holds thresholds, so the views are read from global memory
             // ... and a logged window (gr_advance_chain) always runs the direct back-end, the only one built with the log code
@@ -465,7 +468,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             const uint32_t n = (uint32_t)std::min<uint64_t>(left - left % gran, plan_steps);
             f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
             f.n_steps = n;
-            f.log = cur_log; f.log_pitch = cur_log_pitch; f.log_off = (uint32_t)(step - cur_log_step0);
+            f.log = cur_log; f.log_pitch = cur_log_pitch; f.log_off = (uint32_t)(step - cur_log_step0); f.limit = cur_limit;
             if (strict_fast) {
                 // 4 waves per block share tables and records once there are more 64-chain groups than the chip holds
                 // as single-wave blocks (LDS limits a CU to ~4 blocks)
@@ -894,9 +897,9 @@ GR_VISIBLE int gr_total_samples(gr_sampler *s, uint64_t *out) {
     if (s->o.n_variants > 1) {
         uint64_t t = 0;
         for (uint32_t g = 0; g < s->n_active; ++g) t += s->counted_g[g] * (uint64_t)(s->o.n_chains / s->o.n_variants);
-        *out = t;
+        *out = t - s->skipped_updates;
     } else {
-        *out = s->counted * (uint64_t)s->o.n_chains;
+        *out = s->counted * (uint64_t)s->o.n_chains - s->skipped_updates;
     }
     return GR_OK;
 }
@@ -1091,7 +1094,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
             if (b == 0xffffffffu) throw Error(GR_E_UNSUPPORTED, "ConvergenceWindow too large: a chain group would need more than 2^31 updates");
             worst = std::max(worst, b);
         }
-        const uint64_t L = (uint64_t)worst * batch; // every group runs as long as the slowest one
+        const uint64_t L = (uint64_t)worst * batch; // the window: as long as the slowest group needs; every group executes its own nb * batch steps of it
         // 2. run, logging every step's draws per group: the number of ones when all selectable variables are binary,
         //    else one count per value (generic kernel only)
         bool binary = true;
@@ -1104,14 +1107,21 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         const size_t nH = (size_t)s->o.n_variants * s->H;
         DevBuf<unsigned char> d_log;
         std::vector<uint64_t> c0(nH), c1(nH), c2(nH);
+        DevBuf<uint32_t> d_limit;
         if (logging) {
             d_log.alloc((size_t)n_groups * rows * pitch);
             hip_check(hipMemsetAsync(d_log.p, 0, (size_t)n_groups * rows * pitch, s->stream), "hipMemset");
             s->cur_log = d_log.p; s->cur_log_pitch = (uint32_t)pitch; s->cur_log_rows = rows; s->cur_log_vals = log_vals; s->cur_log_step0 = s->step;
+            // every group stops at its own stopping time, like every reference chain does (chain.go:207-214)
+            std::vector<uint32_t> lim(n_groups);
+            for (uint32_t g = 0; g < n_groups; ++g) lim[g] = nb[g] * batch;
+            d_limit.upload(lim, s->stream);
+            s->cur_limit = d_limit.p;
         }
-        struct Off { gr_sampler *s; ~Off() { s->cur_log = nullptr; s->cur_log_rows = 1; s->cur_log_vals = 1; } } off{s};
+        struct Off { gr_sampler *s; ~Off() { s->cur_log = nullptr; s->cur_limit = nullptr; s->cur_log_rows = 1; s->cur_log_vals = 1; } } off{s};
         if (logging) {
             s->run(L, true);
+            for (uint32_t g = 0; g < n_groups; ++g) s->skipped_updates += 64ull * (L - (uint64_t)nb[g] * batch);
         } else { // no exact rings: fall back to the two halves of the window in time (gr_advance_window)
             if (gr_counts(s, c0.data(), nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
             s->run(L / 2, true);
@@ -1134,7 +1144,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
             a.hoff = d_hoff.p; a.H = (uint32_t)s->H;
             d_hist.alloc((size_t)n_groups * 2u * s->H);
             d_status.alloc(n_groups);
-            hip_check(launch_ring_halves(a, (uint32_t)L, half, d_log.p, (uint32_t)pitch, rows, log_vals, d_hist.p, d_status.p, s->stream), "k_ring_halves");
+            hip_check(launch_ring_halves(a, (uint32_t)L, half, d_log.p, (uint32_t)pitch, rows, log_vals, d_limit.p, d_hist.p, d_status.p, s->stream), "k_ring_halves");
             std::vector<uint32_t> hist((size_t)n_groups * 2u * s->H), status(n_groups);
             hip_check(hipMemcpyAsync(hist.data(), d_hist.p, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
             hip_check(hipMemcpyAsync(status.data(), d_status.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");

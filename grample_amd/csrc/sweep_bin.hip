@@ -205,7 +205,14 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
     uint4 PV = ring_read(1); // plan of the NEXT quad, as uniform VGPRs
 
     unsigned char *logrow = LOG && p.log ? p.log + (size_t)wave_local * p.log_pitch + p.log_off : nullptr;
+    uint32_t lim = 0xffffffffu; // LOG: the group's own stopping time inside the window (SweepParams::limit)
+    if constexpr (LOG)
+        if (p.limit) {
+            const uint32_t t = p.limit[wave_local];
+            lim = t > p.log_off ? t - p.log_off : 0u;
+        }
     auto commit = [&](const Rec &r, const uint32_t val, const uint32_t sidx) {
+        if (LOG && sidx >= lim) return;
         st[r.w[0]] = (unsigned char)val;
         if constexpr (COUNT) {
             const uint32_t ones = (uint32_t)__popcll(__ballot(val != 0));
@@ -422,15 +429,23 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     // A step's value is written at its own level's pass; the counting happens once per step slot after the last pass
     // (histogram adds commute): ones per slot = prefix popcount of the draw mask (V_MBCNT) minus the prefix at the end of
     // the previous DPP row (row_bcast:15) -- valid in lane 15 of every row, the lane that adds to the histogram.
-    auto store = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine) {
-        if (mine) lds[r.h.x + cb] = (unsigned char)val;
+    uint32_t lim = 0xffffffffu; // LOG: the group's own stopping time inside the window (SweepParams::limit)
+    if constexpr (LOG)
+        if (p.limit) {
+            const uint32_t t = p.limit[blockIdx.x];
+            lim = t > p.log_off ? t - p.log_off : 0u;
+        }
+    auto store = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine, const uint32_t sidx) {
+        if (mine && !(LOG && sidx >= lim)) lds[r.h.x + cb] = (unsigned char)val;
     };
     auto count = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const uint32_t sidx) {
         if constexpr (COUNT) {
+            if (LOG && uni_b(sidx & ~3u) >= lim) return; // the whole quad is past the group's stopping time (limits are even,
+                                                         // so a quad is cut between its steps 1 and 2 at most)
             const unsigned long long drawn = __ballot(val != 0u);
             const int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(drawn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)drawn, 0u)) + (int)val;
             const int s1 = incl - __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xe, 0xf, false);
-            if (tail) {
+            if (tail && !(LOG && sidx >= lim)) {
                 lds_u32_t *hp = lds_at(r.h.y); // absolute LDS address (staged records)
                 __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 __hip_atomic_fetch_add(hp + 1, (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -531,18 +546,18 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
             const uint32_t sidx = (g0 + k) * 4u + j;
             uint32_t val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-            store(r, val, lv == 0);
+            store(r, val, lv == 0, sidx);
             if (maxlv >= 1) { // the quad has steps that do not commute: re-gather after the lower levels committed
                 uint32_t v2 = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-                store(r, v2, lv == 1);
+                store(r, v2, lv == 1, sidx);
                 val = lv == 1 ? v2 : val;
                 if (maxlv >= 2) {
                     v2 = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-                    store(r, v2, lv == 2);
+                    store(r, v2, lv == 2, sidx);
                     val = lv == 2 ? v2 : val;
                     if (maxlv >= 3) {
                         v2 = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
-                        store(r, v2, lv == 3);
+                        store(r, v2, lv == 3, sidx);
                         val = lv == 3 ? v2 : val;
                     }
                 }

@@ -213,10 +213,12 @@ int gr_active_groups(gr_sampler *s);
 int gr_advance_window(gr_sampler *s, uint64_t updates_per_chain);
 /* Chain.AdvanceChain (chain.go:180-218) with its own stopping rule: batches of 2 N updates until every
  * selectable variable has been selected cw + 1 more times -- evaluated per 64-chain scan group from the
- * scan stream; every group then runs as long as the slowest one (out_updates, per chain).  The kernels
+ * scan stream; *out_updates = the slowest group's length, by which every chain's stream position advances, while
+ * every group samples only up to its own stopping time (gr_total_samples counts what was sampled).  The kernels
  * log every step's draws per group and the two halves of every ChainHistory ring (the variable's last
  * 2*(cw/2) selections, buffer/circular.go) are rebuilt exactly for gr_adapt / ChainConvergence; a window
- * whose log would exceed 16 GiB keeps the halves of the window in time instead. */
+ * whose log would exceed 16 GiB runs every group for the slowest group's length and keeps the halves of the
+ * window in time instead. */
 int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_updates);
 /* the half-window histograms kept by the last gr_advance_window / gr_advance_chain:
  * first/second [n_variants * total_card] (inactive groups: zeros); *cw = the ConvergenceWindow they stand for */

@@ -67,7 +67,8 @@ class Emulator:
         self.hoff = np.concatenate([[0], np.cumsum(card)]).astype(int)
         self.counts = np.zeros(int(sum(card)), dtype=np.uint64)
         self.step = 0
-        self.record = None  # list of (variable per chain, value per chain) per counted step when set to []
+        self.record = None  # list of (variable per chain, value per chain, live mask) per counted step when set to []
+        self.frozen = np.zeros(n_chains, dtype=bool)  # chains that have finished their AdvanceChain: steps pass, nothing changes
 
     def run(self, n_steps, counting):
         k0, k1 = self.seed & 0xFFFFFFFF, self.seed >> 32
@@ -87,6 +88,8 @@ class Emulator:
             ks = mul_hi(sc, len(self.free))
             vals = np.zeros(self.n_chains, dtype=np.int64)
             for c in range(self.n_chains):
+                if self.frozen[c]:
+                    continue
                 v = self.free[int(ks[c])]
                 T = self.thr(v, self.state[:, c])
                 val = int(np.sum(np.uint64(dr[c]) >= T))
@@ -95,5 +98,5 @@ class Emulator:
                 if counting:
                     self.counts[self.hoff[v] + val] += np.uint64(1)
             if counting and self.record is not None:
-                self.record.append((np.asarray([self.free[int(k)] for k in ks]), vals))
+                self.record.append((np.asarray([self.free[int(k)] for k in ks]), vals, ~self.frozen))
         self.step += n_steps

@@ -314,33 +314,43 @@ def test_many_chains_grouped_chain_per_lane_fast_path(res_dir):
 
 # ------------------------------------------- AdvanceChain: stopping rule + exact ChainHistory halves
 def _expected_rings(em, n, cw, groups):
-    """Replay chain.go:180-218 on the emulator: batches of 2N until every variable of every 64-chain group
-    was selected cw + 1 times; then the halves of every variable's ring (buffer/circular.go:54-84)."""
+    """Replay chain.go:180-218 on the emulator: every 64-chain group runs batches of 2N until each of its variables was
+    selected cw + 1 times and then stops (the others go on); then the halves of every variable's ring
+    (buffer/circular.go:54-84).  Returns (window length = the slowest group's, updates made, first, second)."""
     em.record = []
+    em.frozen[:] = False
     sel = np.zeros((groups, n), dtype=np.int64)
     free = np.asarray(em.free)
-    batches = 0
-    while (sel[:, free] < cw + 1).any():
+    batches, made = 0, 0
+    while not em.frozen.all():
         k0 = len(em.record)
+        live_groups = [gi for gi in range(groups) if not em.frozen[gi * 64]]
         em.run(2 * n, True)
-        for vs, _ in em.record[k0:]:
-            for gi in range(groups):
+        for vs, _, _ in em.record[k0:]:
+            for gi in live_groups:
                 sel[gi, vs[gi * 64]] += 1
+        made += 64 * 2 * n * len(live_groups)
         batches += 1
+        for gi in live_groups:
+            if (sel[gi, free] >= cw + 1).all():
+                em.frozen[gi * 64:(gi + 1) * 64] = True
+    em.frozen[:] = False
     half = cw // 2
     H = int(sum(em.card))
     first, second = np.zeros(H), np.zeros(H)
     for gi in range(groups):
         hist = {int(v): [] for v in free}
-        for vs, vals in em.record:
+        for vs, vals, live in em.record:
+            if not live[gi * 64]:
+                continue
             v = int(vs[gi * 64])
             hist[v].append(np.bincount(vals[gi * 64:(gi + 1) * 64], minlength=em.card[v]))
-        for v, sel in hist.items():
-            ring = sel[-2 * half:]
+        for v, sel_v in hist.items():
+            ring = sel_v[-2 * half:]
             assert len(ring) == 2 * half
             for dst, part in ((first, ring[:half]), (second, ring[half:])):
                 dst[em.hoff[v]:em.hoff[v] + em.card[v]] += np.sum(part, axis=0)
-    return batches * 2 * n, first, second
+    return batches * 2 * n, made, first, second
 
 
 @pytest.mark.parametrize("model,cw,chains,flags,path", [
@@ -363,18 +373,24 @@ def test_advance_chain_stop_rule_and_rings_vs_emulator(res_dir, model, cw, chain
     em = Emulator(pm.card, pm.fixed, free, _thresholds_from_device(s, pm.card), chains, 77)
     s.BurnIn(13); em.run(13, False)  # quad-unaligned start of the window
     L = s.AdvanceChain(cw)
-    eL, efirst, esecond = _expected_rings(em, n, cw, chains // 64)
+    eL, made, efirst, esecond = _expected_rings(em, n, cw, chains // 64)
     assert L == eL
     assert np.array_equal(s.counts()[0], em.counts)
     a, b, got_cw = s.window_halves()
     assert got_cw == cw
     assert np.array_equal(a[0], efirst) and np.array_equal(b[0], esecond)
-    assert s.TotalSampleCount() == chains * L and s.info()["step"] == 13 + L
+    # every group stopped at its own stopping time: the total is what was actually sampled, the position moved by L
+    assert s.TotalSampleCount() == made == int(em.counts.sum()) and made <= chains * L and s.info()["step"] == 13 + L
+    if model == "grid3x3":
+        assert made < chains * L  # the groups of these cases do finish in different batches
+    for c in (0, chains - 1):
+        assert np.array_equal(s.LastSample(c), em.state[:, c])
     # a second window continues from where the first one stopped
     L2 = s.AdvanceChain(cw)
-    eL2, efirst2, esecond2 = _expected_rings(em, n, cw, chains // 64)
+    eL2, made2, efirst2, esecond2 = _expected_rings(em, n, cw, chains // 64)
     a2, b2, _ = s.window_halves()
     assert L2 == eL2 and np.array_equal(a2[0], efirst2) and np.array_equal(b2[0], esecond2)
+    assert s.TotalSampleCount() == made + made2 and np.array_equal(s.counts()[0], em.counts)
 
 
 def test_advance_chain_adaptive_flow_and_fallbacks(res_dir):
