@@ -28,6 +28,10 @@ class SamplerInfo(C.Structure):
                 ("step", u64)]
 
 
+class Position(C.Structure):
+    _fields_ = [("struct_size", u32), ("n_active", u32), ("step", u64), ("counted", u64), ("skipped_updates", u64)]
+
+
 # name -> (restype, argtypes); mirrors include/grample_hip.h one to one
 SIGNATURES = {
     "gr_version": (C.c_char_p, []),
@@ -68,6 +72,10 @@ SIGNATURES = {
     "gr_counts": (C.c_int, [vp, pu64, pu64]),
     "gr_counts_device": (C.c_int, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     "gr_counts_upload": (C.c_int, [vp, pu64]),
+    "gr_get_position": (C.c_int, [vp, C.POINTER(Position), pu64, pu32]),
+    "gr_set_position": (C.c_int, [vp, C.POINTER(Position), pu64, pu32]),
+    "gr_state_download": (C.c_int, [vp, C.POINTER(C.c_uint8)]),
+    "gr_state_upload": (C.c_int, [vp, C.POINTER(C.c_uint8)]),
     "gr_merge": (C.c_int, [C.POINTER(vp), C.c_int, pd, pi32]),
     "gr_merge_local": (C.c_int, [vp, pd, pi32, pd]),
     "gr_allreduce_counts": (C.c_int, [C.POINTER(vp), C.c_int, pu64]),

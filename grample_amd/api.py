@@ -10,7 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import ModelDesc, SamplerInfo, SamplerOpts
+from ._lib import ModelDesc, Position, SamplerInfo, SamplerOpts
 
 GR_FLAG_DIRECT = 1 << 0
 GR_FLAG_SEQUENTIAL = 1 << 1
@@ -301,6 +301,27 @@ class HIPChains:
     def counts_upload(self, counts):
         c = np.ascontiguousarray(counts, dtype=np.uint64)
         _chk(self.L.gr_counts_upload(self.ptr, _p(c, C.c_uint64)))
+
+    def checkpoint(self):
+        """Everything a resumed run needs besides the sampler's construction: chain states, raw counts, position."""
+        pos = Position()
+        pos.struct_size = C.sizeof(Position)
+        cg = np.zeros(self.n_variants, dtype=np.uint64)
+        ep = np.zeros(self.n_variants, dtype=np.uint32)
+        _chk(self.L.gr_get_position(self.ptr, C.byref(pos), _p(cg, C.c_uint64), _p(ep, C.c_uint32)))
+        st = np.zeros((self.n_vars, self.n_chains), dtype=np.uint8)
+        _chk(self.L.gr_state_download(self.ptr, _p(st, C.c_uint8)))
+        return {"states": st, "counts": self.counts(), "counted_per_group": cg, "epoch_per_group": ep,
+                "position": {k: getattr(pos, k) for k, _ in Position._fields_ if k != "struct_size"}}
+
+    def restore(self, ck):
+        st = np.ascontiguousarray(ck["states"], dtype=np.uint8)
+        _chk(self.L.gr_state_upload(self.ptr, _p(st, C.c_uint8)))
+        self.counts_upload(ck["counts"])
+        pos = Position(C.sizeof(Position), *[ck["position"][k] for k, _ in Position._fields_ if k != "struct_size"])
+        cg = np.ascontiguousarray(ck["counted_per_group"], dtype=np.uint64)
+        ep = np.ascontiguousarray(ck["epoch_per_group"], dtype=np.uint32)
+        _chk(self.L.gr_set_position(self.ptr, C.byref(pos), _p(cg, C.c_uint64), _p(ep, C.c_uint32)))
 
     def merge_local(self):
         s, cm = np.zeros(self.H), np.zeros(self.H)

@@ -115,6 +115,7 @@ struct gr_sampler {
     DevBuf<int32_t> d_card, d_fixed;
     DevBuf<unsigned char> d_state;
     DevBuf<unsigned long long> d_counts;
+    DevBuf<unsigned long long> d_reduced; // gr_allreduce_counts: the cross-device total (scratch; d_counts is never overwritten)
     std::vector<VariantDesc> h_variants;
     uint64_t step = 0, counted = 0;
     // adaptive sampler (N2): groups [0, n_active) run; the rest wait to be activated by gr_adapt
@@ -775,7 +776,9 @@ GR_VISIBLE int gr_collapse(gr_sampler *s, uint32_t variant, int32_t var_idx, int
         if (variant >= s->o.n_variants) throw Error(GR_E_INVALID, "variant out of range");
         if (s->started && variant < s->n_active) throw Error(GR_E_STATE, "gr_collapse must precede burn-in / advance (or target a group that is not active yet)");
         s->use();
-        Model &pgm = s->vmodel[variant];
+        // All surgery happens on a copy: Check(), CompileVariant() and configure() can all refuse the result (last free
+        // variable collapsed, LDS layout no longer fits, ...), and a refused Collapse must leave the group exactly as it was.
+        Model pgm = s->vmodel[variant];
         const int N = s->n_vars;
         const auto nbrs = VarNeighbors(pgm);
         if (var_idx < 0) { // gibbs-collapsed.go:102-120: up to N tries among free, un-collapsed variables
@@ -875,14 +878,24 @@ GR_VISIBLE int gr_collapse(gr_sampler *s, uint32_t variant, int32_t var_idx, int
         cv.Marginal = marg.Marginal;
         pgm.Check();
         if (!VarFuncs(pgm)[var_idx].empty()) throw Error(GR_E_COLLAPSE, "Var is collapsed but has a blanket");
-        s->image[variant] = CompileVariant(pgm, CompileLimits{});
+        VariantImage im = CompileVariant(pgm, CompileLimits{}); // refuses a model with nothing left to select (sampler.go:158-160)
+        std::swap(s->image[variant], im);
+        try {
+            s->configure(); // the sampler-wide kernel / LDS choice with the new image in place
+        } catch (...) {
+            std::swap(s->image[variant], im); // refused: put the old image back, and the configuration that goes with it
+            s->configure();
+            throw;
+        }
+        // ---- commit
+        const std::vector<double> marginal = cv.Marginal;
+        s->vmodel[variant] = std::move(pgm);
         s->dirty = true;
-        s->configure();
         s->epoch[variant]++; // base.FunctionsChanged re-draws the start state (gibbs-simple.go:132-142)
         s->init_state(variant);
         s->sync();
         if (out_var) *out_var = var_idx;
-        if (out_marginal) std::copy(cv.Marginal.begin(), cv.Marginal.end(), out_marginal);
+        if (out_marginal) std::copy(marginal.begin(), marginal.end(), out_marginal);
     });
 }
 
@@ -926,6 +939,55 @@ GR_VISIBLE int gr_counts_upload(gr_sampler *s, const uint64_t *counts) {
         if (!s || !counts) throw Error(GR_E_INVALID, "null argument");
         s->use();
         hip_check(hipMemcpyAsync(s->d_counts.p, counts, (size_t)s->o.n_variants * s->H * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream), "H2D");
+        s->sync();
+    });
+}
+
+GR_VISIBLE int gr_get_position(gr_sampler *s, gr_position *pos, uint64_t *counted_per_group, uint32_t *epoch_per_group) {
+    return guarded([&] {
+        if (!s || !pos || pos->struct_size != sizeof(gr_position)) throw Error(GR_E_INVALID, "bad gr_position (struct_size)");
+        pos->n_active = s->n_active;
+        pos->step = s->step;
+        pos->counted = s->counted;
+        pos->skipped_updates = s->skipped_updates;
+        if (counted_per_group) std::copy(s->counted_g.begin(), s->counted_g.end(), counted_per_group);
+        if (epoch_per_group) std::copy(s->epoch.begin(), s->epoch.end(), epoch_per_group);
+    });
+}
+GR_VISIBLE int gr_set_position(gr_sampler *s, const gr_position *pos, const uint64_t *counted_per_group, const uint32_t *epoch_per_group) {
+    return guarded([&] {
+        if (!s || !pos || pos->struct_size != sizeof(gr_position)) throw Error(GR_E_INVALID, "bad gr_position (struct_size)");
+        if (pos->n_active != s->n_active)
+            throw Error(GR_E_STATE, "gr_set_position: the sampler runs " + std::to_string(s->n_active) + " chain groups, the checkpoint " +
+                                        std::to_string(pos->n_active) + " (replay the collapses / activations first)");
+        s->step = pos->step;
+        s->counted = pos->counted;
+        s->skipped_updates = pos->skipped_updates;
+        if (counted_per_group) s->counted_g.assign(counted_per_group, counted_per_group + s->o.n_variants);
+        else if (s->o.n_variants == 1) s->counted_g.assign(1, pos->counted);
+        if (epoch_per_group) s->epoch.assign(epoch_per_group, epoch_per_group + s->o.n_variants);
+        s->started = s->started || pos->step > 0;
+    });
+}
+GR_VISIBLE int gr_state_download(gr_sampler *s, uint8_t *states) {
+    return guarded([&] {
+        if (!s || !states) throw Error(GR_E_INVALID, "null argument");
+        s->use();
+        hip_check(hipMemcpy2DAsync(states, s->o.n_chains, s->d_state.p, s->pitch, s->o.n_chains, s->n_vars, hipMemcpyDeviceToHost, s->stream), "D2H state");
+        s->sync();
+    });
+}
+GR_VISIBLE int gr_state_upload(gr_sampler *s, const uint8_t *states) {
+    return guarded([&] {
+        if (!s || !states) throw Error(GR_E_INVALID, "null argument");
+        for (int v = 0; v < s->n_vars; ++v) {
+            const uint8_t *row = states + (size_t)v * s->o.n_chains;
+            const int C = s->card[v], f = s->fixed[v];
+            for (uint32_t c = 0; c < s->o.n_chains; ++c)
+                if (row[c] >= C || (f >= 0 && row[c] != f)) throw Error(GR_E_INVALID, "state value out of range (or contradicting evidence) for variable " + std::to_string(v));
+        }
+        s->use();
+        hip_check(hipMemcpy2DAsync(s->d_state.p, s->pitch, states, s->o.n_chains, s->o.n_chains, s->n_vars, hipMemcpyHostToDevice, s->stream), "H2D state");
         s->sync();
     });
 }
@@ -1010,15 +1072,25 @@ GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t 
             auto pGroupEnd = reinterpret_cast<ncclResult_t (*)()>(dlsym(h, "ncclGroupEnd"));
             auto pDestroy = reinterpret_cast<ncclResult_t (*)(ncclComm_t)>(dlsym(h, "ncclCommDestroy"));
             if (!pInitAll || !pAllReduce || !pGroupStart || !pGroupEnd || !pDestroy) throw Error(GR_E_NO_DEVICE, "librccl.so lacks the expected symbols");
+            // out of place, into a scratch buffer per device: every sampler's own counts stay what its chains sampled, so
+            // gr_merge / gr_counts / further gr_advance calls after the reduction see unchanged data
+            for (int i = 0; i < n; ++i) { samplers[i]->use(); samplers[i]->d_reduced.alloc(cnt); }
             std::vector<ncclComm_t> comms(n);
             if (pInitAll(comms.data(), n, devs.data()) != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclCommInitAll failed");
             pGroupStart();
             for (int i = 0; i < n; ++i)
-                pAllReduce(samplers[i]->d_counts.p, samplers[i]->d_counts.p, cnt, ncclUint64, ncclSum, comms[i], samplers[i]->stream);
+                pAllReduce(samplers[i]->d_counts.p, samplers[i]->d_reduced.p, cnt, ncclUint64, ncclSum, comms[i], samplers[i]->stream);
             const ncclResult_t r = pGroupEnd();
             for (int i = 0; i < n; ++i) { samplers[i]->use(); samplers[i]->sync(); }
             for (int i = 0; i < n; ++i) pDestroy(comms[i]);
             if (r != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclAllReduce failed");
+            if (out) {
+                gr_sampler *s0 = samplers[0];
+                s0->use();
+                hip_check(hipMemcpyAsync(out, s0->d_reduced.p, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, s0->stream), "D2H");
+                s0->sync();
+            }
+            return;
         }
         if (out && gr_counts(samplers[0], out, nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
     });

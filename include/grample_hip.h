@@ -153,7 +153,32 @@ int gr_counts(gr_sampler *s, uint64_t *counts /*[n_variants*total_card]*/, uint6
 /* device-resident copy of the same array, for an external collective (RCCL
  * through the host framework): pointer stays valid until destroy. */
 int gr_counts_device(gr_sampler *s, void **dptr, size_t *n_elems);
-int gr_counts_upload(gr_sampler *s, const uint64_t *counts); /* restore (checkpoint/resume) */
+int gr_counts_upload(gr_sampler *s, const uint64_t *counts); /* overwrite the raw counts (one part of a checkpoint restore, below) */
+
+/* ------------------------------------------------------ checkpoint / resume
+ * The reference has none (its trace is write-only); with a counter-based RNG a
+ * sampler's whole condition is: the chain states, the raw counts and this
+ * position.  To resume: build the sampler exactly as before (same model, opts,
+ * and the same gr_collapse / gr_activate_group calls with explicit variables),
+ * then gr_state_upload + gr_counts_upload + gr_set_position; every later
+ * gr_burnin / gr_advance continues the Philox streams where the checkpointed
+ * run left them, so the resumed run's counts equal the uninterrupted run's bit
+ * for bit (tests/test_gpu_parity.py::test_checkpoint_resume_is_bit_exact). */
+typedef struct gr_position {
+    uint32_t struct_size;     /* = sizeof(gr_position) */
+    uint32_t n_active;        /* chain groups running (gr_active_groups) */
+    uint64_t step;            /* updates per chain executed so far, burn-in included = position in every Philox stream */
+    uint64_t counted;         /* counted updates per chain (samplers with one group) */
+    uint64_t skipped_updates; /* updates not made inside gr_advance_chain windows by groups that stopped early */
+} gr_position;
+/* counted_per_group [n_variants] (counted updates per chain of each group) and
+ * epoch_per_group [n_variants] (start-state re-draw counter, gibbs-simple.go:132-142) may be NULL */
+int gr_get_position(gr_sampler *s, gr_position *pos, uint64_t *counted_per_group, uint32_t *epoch_per_group);
+/* pos->n_active must equal the sampler's: groups are re-created by replaying the collapses, not by this call */
+int gr_set_position(gr_sampler *s, const gr_position *pos, const uint64_t *counted_per_group, const uint32_t *epoch_per_group);
+/* Chain.LastSample of every chain: states[v * n_chains + chain], one byte per variable and chain */
+int gr_state_download(gr_sampler *s, uint8_t *states /*[n_vars*n_chains]*/);
+int gr_state_upload(gr_sampler *s, const uint8_t *states /*[n_vars*n_chains]*/);
 
 /* MergeChains (chain.go:96-148) over all chains of `n` samplers (= devices),
  * in global variant order: a variable collapsed in ANY group takes the first
@@ -167,8 +192,10 @@ int gr_merge(gr_sampler *const *samplers, int n, double *out_marginal, int32_t *
 int gr_merge_local(gr_sampler *s, double *out_sum /*[total_card]*/, int32_t *out_coll_variant /*[n_vars], -1 = none*/,
                    double *out_coll_marginal /*[total_card]*/);
 /* Sum of the raw count arrays of n samplers living in ONE process, one per
- * device, with a single ncclAllReduce(sum, uint64) over RCCL; every sampler's
- * device array then holds the total.  out may be NULL. */
+ * device, with a single ncclAllReduce(sum, uint64) over RCCL, OUT OF PLACE: the
+ * total lands in a scratch buffer per device and in out; every sampler's own
+ * counts stay what its chains sampled, so gr_merge, gr_counts and further
+ * gr_advance calls are unaffected.  out may be NULL. */
 int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t *out /*[n_variants*total_card]*/);
 
 /* Chain.LastSample of one chain (chain.go:19) */

@@ -116,6 +116,26 @@ def test_collapse_refusals(res_dir):
         s2.Collapse(0, big[0])  # 16^6 entries > maxTabSize 2^23
 
 
+def test_refused_collapse_leaves_the_group_untouched():
+    """A Collapse that is refused AFTER the model surgery (here: the only free variable, whose neighbour is evidence --
+    nothing would be left to select) must not leave a half-collapsed group behind: the variable is still sampled, the
+    merge shows no collapsed variable and its conditional is still served."""
+    m = g.Model.from_arrays([2, 2], [[0], [0, 1]], [[0.3, 0.7], [1.0, 2.0, 3.0, 0.5]], fixed=[-1, 1])
+    s = g.HIPChains.NewGibbsCollapsed(m, 64, 1, seed=5)
+    before = s.conditional(0, 0, [0, 1])
+    with pytest.raises(g.GrError) as ei:
+        s.Collapse(0, 0)
+    assert "No Variables to select" in str(ei.value)
+    assert np.array_equal(s.conditional(0, 0, [0, 1]), before)
+    assert s.BlanketSize(0, 0) == 2 and s.FunctionCount(0, 0) == 2
+    s.BurnIn(8); s.Advance(100)
+    merged, coll = g.MergeChains([s])
+    assert coll.tolist() == [0, 0]
+    assert s.counts()[0][:2].sum() == 64 * 100
+    p1 = 0.7 * 0.5 / (0.3 * 2.0 + 0.7 * 0.5)
+    assert merged[0][1] / merged[0].sum() == pytest.approx(p1, abs=0.03)
+
+
 def test_merge_chains_semantics(res_dir):
     """chain_test.go:11-80 TestMergeChains, on device-held counts: sums include each chain's 1/Card
     prior; a variable collapsed in any group takes that group's exact marginal un-summed."""

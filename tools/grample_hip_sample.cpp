@@ -8,7 +8,9 @@
 //
 //   grample_hip_sample -m MODEL.uai [-s simple|collapsed|adaptive] [-o] [-d] [-c CHAINS] [-k GROUPS]
 //                      [-b BURNIN] [-i MAXITERS] [-r ROUNDS] [-w CWIN] [-e SEED] [--device N]
-//   -w CWIN: every round is one Chain.AdvanceChain with ConvergenceWindow CWIN (chain.go:180-218) instead of MAXITERS/ROUNDS updates
+//   -i MAXITERS: like the reference's --maxiters it bounds the TOTAL sample count over all chains (root.go:482-496: the loop
+//      ends once sampleCount > maxIters); a round advances every chain by ceil(MAXITERS / (ROUNDS * CHAINS)) updates
+//   -w CWIN: every round is one Chain.AdvanceChain with ConvergenceWindow CWIN (chain.go:180-218) instead
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -96,8 +98,10 @@ int main(int argc, char **argv) {
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<double> merged(H);
     std::vector<int32_t> coll(n);
-    const uint64_t per_round = (uint64_t)std::max(1L, maxiters / std::max(1L, rounds));
-    double es[8];
+    // --maxiters counts samples over ALL chains (root.go:486-496), so one round gives every chain its share of it
+    const uint64_t per_round = (uint64_t)std::max(1L, (maxiters + rounds * chains - 1) / std::max(1L, rounds * chains));
+    double es[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool scored = false;
     for (long r = 0; r < rounds; ++r) {
         if (cwin > 0) {
             uint64_t ran = 0;
@@ -113,8 +117,10 @@ int main(int argc, char **argv) {
         if (use_solution) {
             if (gr_error_suite(n, card.data(), nullptr, fixed.data(), sol.data(), merged.data(), es)) die("Error calculating score");
             std::printf(" | MeanHellinger %.6f MaxHellinger %.6f MeanMAE %.6f", es[2], es[6], es[0]);
+            scored = true;
         }
         std::printf("\n");
+        if (cwin <= 0 && samples > (uint64_t)maxiters) break; // root.go:493-496: sampleCount > maxIters ends the run
         if (adaptive && r < rounds / 2) { // adaptation only during the first half of the run (root.go:469,542-547)
             std::vector<int32_t> nv(4);
             uint32_t nn = 0;
@@ -124,7 +130,7 @@ int main(int argc, char **argv) {
         }
     }
     std::printf("DONE\n");
-    if (use_solution) std::printf("FINAL MeanHellinger=%.8f MaxHellinger=%.8f MeanJS=%.8f MaxJS=%.8f\n", es[2], es[6], es[3], es[7]);
+    if (use_solution && scored) std::printf("FINAL MeanHellinger=%.8f MaxHellinger=%.8f MeanJS=%.8f MaxJS=%.8f\n", es[2], es[6], es[3], es[7]);
     gr_sampler_destroy(s);
     gr_model_destroy(m);
     return 0;
