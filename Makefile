@@ -20,7 +20,7 @@ all: $(LIB) oracle $(TOOL)
 $(TOOL): tools/grample_hip_sample.cpp include/grample_hip.h $(LIB)
 	g++ -O2 -std=c++17 -Wall -o $@ $< -Lgrample_amd -lgrample_hip -Wl,-rpath,'$$ORIGIN/../grample_amd' -Wl,-rpath,/opt/rocm/lib
 
-$(OBJDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h
+$(OBJDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/cond.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -1,0 +1,124 @@
+// The conditional law of one Gibbs update on the device: from the Card summed log potentials of a
+// variable to its cumulative draw thresholds.  ONE definition, shared by every kernel (direct sweep,
+// memoisation, probe, and the value-parallel sweep in sweep_pw4.hip), so that all of them produce the
+// same thresholds bit for bit.
+//
+// Reference (sampler/gibbs-simple.go:227-258 + sampler/sampler.go:110-123):
+//   shift so min(w) = 1.5 when min < -8; w = exp(w); tot = sum w; then SEQUENTIALLY for i:
+//     if w_i / tot < 1e-6 { d = tot * 1e-6; tot += d; w_i += d }
+//   WeightedSample re-sums the weights, r = U * tot2, picks the first i with r <= cum_i.
+// Here:
+//   d_i   = (double) __expf(w_i - max w)               shift by the max: identical after normalisation
+//   sums  : values are grouped in BLOCKS of 4 (block b = values 4b .. 4b+3, summed left to right);
+//           the (at most 4) block sums q_b of a group of 16 values are combined as
+//               prefix of block 1 = q0, of block 2 = q0 + q1, of block 3 = (q1 + q2) + q0,
+//               total = (q2 + q3) + (q0 + q1)          (absent blocks count as +0.0, which is exact)
+//           -- a fixed summation order that a lane-per-chain loop and a 4-lanes-per-chain scan both
+//           reproduce exactly (f64; any order is within 1e-16 of the reference's left-to-right sum)
+//   floor : thr = 1e-6 * total; SEQUENTIALLY for i: if d_i < thr { d_i += thr; thr += 1e-6 * thr }
+//           -- the reference's rule with thr standing for tot * 1e-6 (its delta): same predicate, same
+//           increments, the running total advanced by the same recurrence
+//   draw  : value = #{ i < Card-1 : u >= T_i },  u a 32-bit uniform,
+//           T_i = min(rint(cum_i * 2^32 / total'), 2^32 - 1), total' and cum_i re-summed after the
+//           floor in the block order above (cum inside a block: prefix of the block, then left to right)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gr {
+
+constexpr double kFloorEps = 1e-6; // gibbs-simple.go:248 (probability floor), also the growth of the running total
+
+// one floor step of the sequential rule: value d against the current threshold thr (= 1e-6 x running total)
+__device__ __forceinline__ void floor_step(double &d, double &thr, const bool live) {
+    const double fs = (live && d < thr) ? 1.0 : 0.0;
+    d = fma(fs, thr, d);                 // d += thr when floored (fs * thr is exact)
+    thr = fma(fs * kFloorEps, thr, thr); // the running total grows by its 1e-6 (gibbs-simple.go:255-257)
+}
+
+// Thresholds as f64 integers in [0, 2^32 - 1] (compare with (double)u; store as u32 for the memoised tables).
+// FULL = the variable uses all MAXC values: same arithmetic, none of the per-value `i < C` guards.
+template <int MAXC, bool FULL>
+__device__ __forceinline__ void thresholds_impl(const float (&w)[MAXC], const int C, double (&T)[MAXC > 1 ? MAXC - 1 : 1]) {
+    constexpr int NB = (MAXC + 3) / 4; // blocks of 4 values
+    constexpr int NG = (NB + 3) / 4;   // groups of 4 blocks
+    float m = w[0];
+#pragma unroll
+    for (int i = 1; i < MAXC; ++i)
+        if (FULL || i < C) m = fmaxf(m, w[i]);
+    double d[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) d[i] = (FULL || i < C) ? (double)__expf(w[i] - m) : 0.0;
+
+    // block sums, block prefixes P[b] (sum of the blocks before b; P[0] is unused) and the total
+    double P[NB];
+    auto sums = [&]() -> double {
+        double q[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            q[b] = d[4 * b];
+#pragma unroll
+            for (int k = 1; k < 4; ++k)
+                if (4 * b + k < MAXC) q[b] += d[4 * b + k];
+        }
+        double base = 0.0; // total of the groups before the current one
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const int b0 = 4 * g, nb = (NB - b0) < 4 ? (NB - b0) : 4;
+            auto qb = [&](int j) -> double { return q[b0 + j < NB ? b0 + j : NB - 1]; }; // (index clamped: never read past nb)
+            double z[4] = {qb(0), 0.0, 0.0, 0.0}; // inclusive prefix inside the group
+            if (nb > 1) z[1] = qb(0) + qb(1);
+            if (nb > 2) z[2] = (qb(1) + qb(2)) + qb(0);
+            if (nb > 3) z[3] = (qb(2) + qb(3)) + z[1];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (j < nb) {
+                    if (g == 0) { if (j > 0) P[b0 + j] = z[j - 1]; }
+                    else P[b0 + j] = j > 0 ? base + z[j - 1] : base;
+                }
+            base = g == 0 ? z[nb - 1] : base + z[nb - 1];
+        }
+        return base;
+    };
+
+    double thr = kFloorEps * sums();
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) floor_step(d[i], thr, FULL || i < C); // every value must stay possible (gibbs-simple.go:246-258)
+
+    const double scale = 4294967296.0 / sums(); // WeightedSample re-sums the weights (sampler.go:110-116)
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        double cum = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = 4 * b + k;
+            if (i < MAXC - 1) {
+                cum = (k == 0) ? (b == 0 ? d[i] : P[b] + d[i]) : cum + d[i];
+                if (FULL || i < C - 1) T[i] = fmin(rint(cum * scale), 4294967295.0);
+            }
+        }
+    }
+}
+
+template <int MAXC>
+__device__ __forceinline__ void thresholds(const float (&w)[MAXC], const int C, double (&T)[MAXC > 1 ? MAXC - 1 : 1]) {
+    if (C == MAXC) thresholds_impl<MAXC, true>(w, C, T);
+    else thresholds_impl<MAXC, false>(w, C, T);
+}
+
+template <int MAXC>
+__device__ __forceinline__ uint32_t pick(const double (&T)[MAXC > 1 ? MAXC - 1 : 1], const int C, const uint32_t u) {
+    const double uf = (double)u;
+    uint32_t val = 0;
+    if (C == MAXC) {
+#pragma unroll
+        for (int i = 0; i < MAXC - 1; ++i) val += (uf >= T[i]) ? 1u : 0u;
+    } else {
+#pragma unroll
+        for (int i = 0; i < MAXC - 1; ++i)
+            if (i < C - 1) val += (uf >= T[i]) ? 1u : 0u;
+    }
+    return val;
+}
+
+} // namespace gr

@@ -26,78 +26,12 @@
 #include "device_layout.h"
 #include "kernels.h"
 #include "philox.h"
+#include "cond.h"
 
 namespace gr {
 
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-
-// Cumulative draw thresholds of the conditional given the C summed log
-// potentials w[] (gibbs-simple.go:227-258 + sampler.go:110-123).
-//   reference: shift so min(w) = 1.5 when min < -8, exp, tot = sum, then
-//   SEQUENTIALLY for i: if w_i/tot < 1e-6 { d = tot*1e-6; tot += d; w_i += d },
-//   then WeightedSample re-sums and picks the first i with r <= cum_i, r = U*tot.
-// here: shift by max(w) instead (identical after normalisation; keeps f32 exp in
-// range), f32 exp, everything after it in f64 like the reference.  The draw is
-// "value = #{ i : u >= T_i }" with u a 32-bit uniform and T_i = round(cum_i/tot * 2^32).
-// FULL = the variable uses all MAXC values: same arithmetic, none of the per-value `i < C` scalar guards.
-template <int MAXC, bool FULL>
-__device__ __forceinline__ void thresholds_impl(const float (&w)[MAXC], const int C, uint32_t (&T)[MAXC > 1 ? MAXC - 1 : 1]) {
-    float m = w[0];
-#pragma unroll
-    for (int i = 1; i < MAXC; ++i)
-        if (FULL || i < C) m = fmaxf(m, w[i]);
-    double d[MAXC];
-    double tot = 0.0;
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-        if (FULL || i < C) {
-            d[i] = (double)__expf(w[i] - m);
-            tot += d[i];
-        }
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-        if (FULL || i < C) {
-            if (d[i] < 1e-6 * tot) { // every value must stay possible (gibbs-simple.go:246-258)
-                const double delta = tot * 1e-6;
-                tot += delta;
-                d[i] += delta;
-            }
-        }
-    double tot2 = 0.0; // WeightedSample re-sums the weights (sampler.go:110-116)
-#pragma unroll
-    for (int i = 0; i < MAXC; ++i)
-        if (FULL || i < C) tot2 += d[i];
-    const double scale = 4294967296.0 / tot2;
-    double cum = 0.0;
-#pragma unroll
-    for (int i = 0; i < MAXC - 1; ++i)
-        if (FULL || i < C - 1) {
-            cum += d[i];
-            const double t = fmin(rint(cum * scale), 4294967295.0);
-            T[i] = (uint32_t)t;
-        }
-}
-
-template <int MAXC>
-__device__ __forceinline__ void thresholds(const float (&w)[MAXC], const int C, uint32_t (&T)[MAXC > 1 ? MAXC - 1 : 1]) {
-    if (C == MAXC) thresholds_impl<MAXC, true>(w, C, T);
-    else thresholds_impl<MAXC, false>(w, C, T);
-}
-
-template <int MAXC>
-__device__ __forceinline__ uint32_t pick(const uint32_t (&T)[MAXC > 1 ? MAXC - 1 : 1], const int C, const uint32_t u) {
-    uint32_t val = 0;
-    if (C == MAXC) {
-#pragma unroll
-        for (int i = 0; i < MAXC - 1; ++i) val += (u >= T[i]) ? 1u : 0u;
-    } else {
-#pragma unroll
-        for (int i = 0; i < MAXC - 1; ++i)
-            if (i < C - 1) val += (u >= T[i]) ? 1u : 0u;
-    }
-    return val;
-}
 
 // Summed log potentials of variable `pg` (its direct program) for every
 // candidate value, reading neighbour values through `get(var)`.
@@ -285,7 +219,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
             float w[MAXC];
             if constexpr (PW) log_weights_pw<MAXC, (MAXC <= 16 ? 8 : (MAXC <= 32 ? 4 : 2))>(pg, tab_f, get, w, p0, p1, p2, conflict);
             else log_weights<MAXC>(pg, tab_f, get, w, p0, p1, p2, conflict);
-            uint32_t Th[MAXC > 1 ? MAXC - 1 : 1];
+            double Th[MAXC > 1 ? MAXC - 1 : 1];
             thresholds<MAXC>(w, C, Th);
             return pick<MAXC>(Th, C, u);
         }
@@ -433,12 +367,12 @@ __global__ void k_build_cpt(const VariantDesc vd, const uint32_t *progs_all, con
     float w[MAXC];
     bool c = false;
     log_weights<MAXC>(pg, views_all + vd.views_base, get, w, 0xffffffffu, 0xffffffffu, 0xffffffffu, c);
-    uint32_t Th[MAXC > 1 ? MAXC - 1 : 1];
+    double Th[MAXC > 1 ? MAXC - 1 : 1];
     thresholds<MAXC>(w, C, Th);
     uint32_t *row = cpt_all + vd.cpt_base + cp[2] + cfg * (uint32_t)(C - 1);
 #pragma unroll
     for (int i = 0; i < MAXC - 1; ++i)
-        if (i < C - 1) row[i] = Th[i];
+        if (i < C - 1) row[i] = (uint32_t)Th[i]; // integers in [0, 2^32 - 1]: u >= row[i] is the direct path's (double)u >= Th[i]
 }
 
 // Probe: the conditional the sampling kernels use, for one variable and one
@@ -452,11 +386,11 @@ __global__ void k_conditional(const VariantDesc vd, const uint32_t *progs_all, c
     float w[MAXC];
     bool c = false;
     log_weights<MAXC>(pg, views_all + vd.views_base, get, w, 0xffffffffu, 0xffffffffu, 0xffffffffu, c);
-    uint32_t Th[MAXC > 1 ? MAXC - 1 : 1];
+    double Th[MAXC > 1 ? MAXC - 1 : 1];
     thresholds<MAXC>(w, C, Th);
     double prev = 0.0;
     for (int i = 0; i < C; ++i) {
-        const double cur = (i < C - 1) ? (double)Th[i < MAXC - 1 ? i : 0] : 4294967296.0;
+        const double cur = (i < C - 1) ? Th[i < MAXC - 1 ? i : 0] : 4294967296.0;
         probs[i] = (cur - prev) / 4294967296.0;
         prev = cur;
     }
