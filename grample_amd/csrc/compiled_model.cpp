@@ -98,6 +98,8 @@ VariantImage CompileVariant(const Model &m, const CompileLimits &lim) {
         }
     }
     while (im.views.size() % 4) im.views.push_back(0.f);
+    im.zero_row = (uint32_t)im.views.size();
+    im.views.resize(im.views.size() + 64, 0.f); // an all-zero row: what the padding slots of the value-parallel programs read
 
     // ---- pairwise fixed-stride form of the same programs
     im.pairwise = true;
@@ -125,6 +127,25 @@ VariantImage CompileVariant(const Model &m, const CompileLimits &lim) {
             }
         }
         while (im.pprog.size() % 4) im.pprog.push_back(0);
+        // value-parallel form: byte offsets, LDS row offsets, slots padded to 8 with the zero row
+        im.vprog_off.assign(N, 0);
+        for (int v = 0; v < N; ++v) {
+            im.vprog_off[v] = (uint32_t)im.vprog.size();
+            const uint32_t *pg = im.pprog.data() + im.pprog_off[v];
+            const uint32_t nf = pg[0] >> 16, slots = (nf + 7u) & ~7u;
+            im.vprog.push_back((pg[0] & 0xffffu) | (slots << 16));
+            im.vprog.push_back(pg[1]);
+            im.vprog.push_back(0);
+            im.vprog.push_back(0);
+            for (uint32_t f = 0; f < slots; ++f) {
+                const uint32_t *e = pg + 4 + 4 * f;
+                const bool real = f < nf;
+                im.vprog.push_back((real ? e[0] : im.zero_row) * 4u);
+                im.vprog.push_back((real ? e[1] : (uint32_t)v) * 64u);
+                im.vprog.push_back(real ? e[2] * 4u : 0u);
+                im.vprog.push_back(0);
+            }
+        }
     }
 
     // ---- memoised programs: blanket (minus evidence variables, whose value is a constant)

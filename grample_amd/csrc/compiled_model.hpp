@@ -40,6 +40,12 @@ struct VariantImage {
     // fixed stride => every factor's entry is an independent scalar load.
     bool pairwise = false;
     std::vector<uint32_t> pprog, pprog_off;
+    // value-parallel form of the pairwise program (k_sweep_pw4), per variable:
+    //   [0] Card | rowlen << 8 | n_slots << 16 (n_slots = factors rounded up to 8), [1] histogram offset, [2..3] pad, then per
+    //   slot one 16-byte entry {view BYTE offset, other var * 64 (its LDS state row), BYTE stride, 0}; the slots past the
+    //   last factor point at the all-zero row `zero_row` with stride 0, so the kernel needs no guards.
+    std::vector<uint32_t> vprog, vprog_off;
+    uint32_t zero_row = 0;          // float offset of an all-zero row (64 floats) at the end of `views`
     std::vector<uint32_t> free_vars;// selectable variables: FixedVal < 0 and not Collapsed (sampler.go:146-156)
     bool cpt_ok = false;            // memoised path available
     std::vector<uint32_t> cprog;    // memoised programs

@@ -18,6 +18,7 @@ struct VariantDesc {
     uint32_t cpt_len;      // words
     uint32_t rec_base;     // records (kRecDwords each), into recs: one per entry of this group's free list
     uint32_t pprog_base;   // words, into pprogs (pairwise fixed-stride direct programs); pprog_off shares progoff_base
+    uint32_t vprog_base;   // words, into vprogs (value-parallel pairwise programs, k_sweep_pw4); vprog_off shares progoff_base
 };
 
 struct SweepParams {
@@ -31,6 +32,8 @@ struct SweepParams {
     const uint32_t *cpt;
     const uint32_t *pprogs;     // pairwise fixed-stride direct programs (null unless every group is pairwise)
     const uint32_t *pprog_off;
+    const uint32_t *vprogs;     // value-parallel pairwise programs (k_sweep_pw4), same condition
+    const uint32_t *vprog_off;
     unsigned char *state;       // [n_vars][pitch] chain-minor: one coalesced 64-B line per wave per variable
     unsigned long long *counts; // [n_variants][H]
     uint32_t n_vars;

@@ -264,7 +264,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
         // which variable each of the next 4 steps updates: wave-uniform stream -> SALU
         const u32x4 sc = PC ? philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_SCAN_CHAIN + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi)
-                            : philox4x32_10(q_lo, q_hi, wave_gid, DOM_SCAN, p.seed_lo, p.seed_hi);
+                            : philox4x32_10<true>(q_lo, q_hi, wave_gid, DOM_SCAN, p.seed_lo, p.seed_hi);
         // the 4 categorical draws of this chain
         const u32x4 dr = philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
         const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w};

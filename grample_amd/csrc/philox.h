@@ -43,14 +43,17 @@ GR_HD uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) {
 #endif
 }
 
+// UNIFORM = every argument is wave-uniform (the per-group scan stream): plain xors, so that the whole block stays on the
+// scalar unit -- V_BITOP3 exists on the vector unit only and would drag a uniform Philox call onto it
+template <bool UNIFORM = false>
 GR_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
         const uint64_t p0 = (uint64_t)PHILOX_M0 * c0;
         const uint64_t p1 = (uint64_t)PHILOX_M1 * c2;
-        const uint32_t n0 = xor3((uint32_t)(p1 >> 32), c1, k0);
+        const uint32_t n0 = UNIFORM ? ((uint32_t)(p1 >> 32) ^ c1 ^ k0) : xor3((uint32_t)(p1 >> 32), c1, k0);
         const uint32_t n1 = (uint32_t)p1;
-        const uint32_t n2 = xor3((uint32_t)(p0 >> 32), c3, k1);
+        const uint32_t n2 = UNIFORM ? ((uint32_t)(p0 >> 32) ^ c3 ^ k1) : xor3((uint32_t)(p0 >> 32), c3, k1);
         const uint32_t n3 = (uint32_t)p0;
         c0 = n0; c1 = n1; c2 = n2; c3 = n3;
         k0 += PHILOX_W0;

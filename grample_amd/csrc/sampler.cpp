@@ -105,11 +105,13 @@ struct gr_sampler {
     bool par_packed = false;          // step-parallel records use one dword per neighbour
     uint32_t rec_stride = 64;         // bytes per record (128 when a variable has 13..16 neighbours)
     bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
+    bool pw4 = false;                 // value-parallel form of the direct path (k_sweep_pw4): pairwise, 8 < Card <= 16
+    uint32_t pw4_hist_off = 0, pw4_lds = 0;
     bool strict_fast = false;         // GR_FLAG_SCAN_PER_CHAIN on memoised tables (k_sweep_strict, the 4-lane form's LDS layout)
     uint32_t par_hist_off = 0, par_tab_off = 0, par_rec_off = 0, par_plan_off = 0, par_scr_off = 0, par_lds = 0;
     // device pools
     DevBuf<VariantDesc> d_variants;
-    DevBuf<uint32_t> d_progs, d_prog_off, d_free, d_cprogs, d_cprog_off, d_cpt, d_pprogs, d_pprog_off;
+    DevBuf<uint32_t> d_progs, d_prog_off, d_free, d_cprogs, d_cprog_off, d_cpt, d_pprogs, d_pprog_off, d_vprogs, d_vprog_off;
     bool pairwise = false;            // every group's model has arity <= 2: fixed-stride direct programs
     DevBuf<float> d_views;
     DevBuf<int32_t> d_card, d_fixed;
@@ -143,6 +145,7 @@ struct gr_sampler {
     void sync() { hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
 
     void configure();
+    void configure_paths();
     void configure_impl(bool try_strict_fast);
     void rebuild();
     void init_state(uint32_t variant);
@@ -152,6 +155,22 @@ struct gr_sampler {
 
 // Pick block size, LDS layout and conditional path for the current images.
 void gr_sampler::configure() {
+    configure_paths();
+    // value-parallel direct form: every group pairwise, the direct path chosen, Card 9..16, whole 64-chain scan groups
+    pw4 = false;
+    bool all_pw = true;
+    for (const auto &im : image) all_pw = all_pw && im.pairwise;
+    if (all_pw && !fast && !cpt && max_card > 8 && max_card <= 16 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE)) &&
+        o.fast_form != 1 && (o.n_chains % 64u) == 0 && (o.n_variants == 1 || cpv % 64u == 0) && !o.block_threads) {
+        pw4_hist_off = ((uint32_t)n_vars * 64u + 15u) & ~15u;
+        pw4_lds = pw4_hist_off + 4u * (uint32_t)H * 4u;
+        // measured on ObjectDetection_13: 1.9x the chain-per-lane form at 32 768 chains (2 wavefronts per SIMD instead of
+        // one on half of the SIMDs), still 1.5x at 262 144 (fewer table bytes in flight per wavefront) -- so: whenever it fits
+        pw4 = pw4_lds <= kLdsBudget;
+    }
+}
+
+void gr_sampler::configure_paths() {
     strict_fast = false;
     if ((o.flags & GR_FLAG_SCAN_PER_CHAIN) && !(o.flags & GR_FLAG_DIRECT)) {
         // strict mode first tries the memoised tables in the 4-lane form's LDS layout (k_sweep_strict)
@@ -268,7 +287,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
 void gr_sampler::rebuild() {
     use();
     configure();
-    std::vector<uint32_t> progs, prog_off, freev, cprogs, cprog_off, pprogs, pprog_off;
+    std::vector<uint32_t> progs, prog_off, freev, cprogs, cprog_off, pprogs, pprog_off, vprogs, vprog_off;
     pairwise = true;
     for (const auto &im : image) pairwise = pairwise && im.pairwise;
     std::vector<float> views;
@@ -290,6 +309,9 @@ void gr_sampler::rebuild() {
         vd.pprog_base = (uint32_t)pprogs.size();
         pprogs.insert(pprogs.end(), im.pprog.begin(), im.pprog.end());
         pprog_off.insert(pprog_off.end(), im.pprog_off.begin(), im.pprog_off.end());
+        vd.vprog_base = (uint32_t)vprogs.size();
+        vprogs.insert(vprogs.end(), im.vprog.begin(), im.vprog.end());
+        vprog_off.insert(vprog_off.end(), im.vprog_off.begin(), im.vprog_off.end());
         progs.insert(progs.end(), im.prog.begin(), im.prog.end());
         prog_off.insert(prog_off.end(), im.prog_off.begin(), im.prog_off.end());
         views.insert(views.end(), im.views.begin(), im.views.end());
@@ -308,6 +330,9 @@ void gr_sampler::rebuild() {
     pprogs.resize(pprogs.size() + 4, 0);
     d_pprogs.upload(pprogs, stream);
     d_pprog_off.upload(pprog_off, stream);
+    vprogs.resize(vprogs.size() + 4, 0);
+    d_vprogs.upload(vprogs, stream);
+    d_vprog_off.upload(vprog_off, stream);
     d_cpt.alloc(cpt_total + 4);
     hip_check(hipMemsetAsync(d_cpt.p, 0, (cpt_total + 4) * sizeof(uint32_t), stream), "hipMemset");
     if (cpt)
@@ -396,6 +421,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     p.progs = d_progs.p; p.prog_off = d_prog_off.p; p.views = d_views.p; p.free_vars = d_free.p;
     p.cprogs = d_cprogs.p; p.cprog_off = d_cprog_off.p; p.cpt = d_cpt.p;
     p.pprogs = d_pprogs.p; p.pprog_off = d_pprog_off.p;
+    p.vprogs = d_vprogs.p; p.vprog_off = d_vprog_off.p;
     p.state = d_state.p; p.counts = d_counts.p;
     const uint32_t act = active_chains();
     p.n_vars = (uint32_t)n_vars; p.H = (uint32_t)H; p.chain0 = 0; p.n_chains = act; p.pitch = pitch;
@@ -419,6 +445,11 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             // area holds thresholds, so the views are read from global memory
             // ... and a logged window (gr_advance_chain) always runs the direct back-end, the only one built with the log code
             const bool plain = strict_fast || cur_log != nullptr;
+            if (pw4 && !cur_log) { // (a logged window runs the chain-per-lane kernel, the only one built with the log code)
+                p.lds_hist_off = pw4_hist_off;
+                hip_check(launch_sweep_pw4(p, act / 64u, pw4_lds, stream), "k_sweep_pw4 launch");
+                p.lds_hist_off = lds_hist_off;
+            } else
             hip_check(launch_sweep(p, max_card, cpt && !plain, tab_lds && !plain, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0,
                                    (act + T - 1) / T, T, lds, stream), "k_sweep launch");
             step += n;
@@ -521,6 +552,7 @@ void gr_sampler::burn_group(uint32_t group, uint32_t updates) {
     p.progs = d_progs.p; p.prog_off = d_prog_off.p; p.views = d_views.p; p.free_vars = d_free.p;
     p.cprogs = d_cprogs.p; p.cprog_off = d_cprog_off.p; p.cpt = d_cpt.p;
     p.pprogs = d_pprogs.p; p.pprog_off = d_pprog_off.p;
+    p.vprogs = d_vprogs.p; p.vprog_off = d_vprog_off.p;
     p.state = d_state.p; p.counts = d_counts.p;
     p.n_vars = (uint32_t)n_vars; p.H = (uint32_t)H; p.pitch = pitch; p.chains_per_variant = cpv;
     p.chain0 = group * cpv; p.n_chains = (group + 1) * cpv;
@@ -1422,7 +1454,7 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         if (!s || !out || out->struct_size != sizeof(gr_sampler_info)) throw Error(GR_E_INVALID, "bad gr_sampler_info");
         if (s->dirty) { s->use(); s->configure(); }
         out->block_threads = s->T; out->n_blocks = s->blocks; out->lds_bytes = s->lds;
-        out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->cpt ? 1u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
+        out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->cpt ? 1u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

@@ -117,7 +117,8 @@ typedef struct gr_sampler_opts {
     uint32_t variant_offset; /* global index of this device's variant 0 */
     uint32_t flags;          /* GR_FLAG_* */
     uint32_t block_threads;  /* 0 = auto; else 64/128/256 */
-    uint32_t fast_form;      /* tuning of the binary fast path: 0 = auto; 1 = chain per lane; 2 = 4 lanes per chain;
+    uint32_t fast_form;      /* kernel form: 0 = auto; 1 = chain per lane; 2 = 4 lanes per chain (binary memoised models: one lane per step
+                                of a quad; large-Card pairwise models on the direct path: one lane per block of 4 values);
                                 4, 5, 6 = 4 lanes per chain with the step records read from LDS one by one / from LDS together /
                                 from global memory one iteration ahead (2 picks by occupancy) */
 } gr_sampler_opts;
@@ -215,7 +216,8 @@ typedef struct gr_sampler_info {
     uint32_t block_threads;
     uint32_t n_blocks;
     uint32_t lds_bytes;
-    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path), 3 = same, 4 lanes per chain, 5 = strict per-chain scan on memoised tables */
+    uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path), 3 = same, 4 lanes per chain, 5 = strict per-chain scan on memoised tables,
+                               6 = direct conditional, value-parallel (4 lanes per chain, pairwise models with 8 < Card <= 16) */
     uint32_t max_card;
     uint32_t tables_in_lds;
     uint32_t n_launches_last;

@@ -270,6 +270,43 @@ def test_all_kernel_forms_agree_bit_for_bit(res_dir):
         assert np.array_equal(runs[0][2], runs[k][2]), k
 
 
+def _pairwise_big_card_model(rng, n=24):
+    """random pairwise model with Card up to 16, evidence, and many near-zero entries (so that most updates floor several
+    values and some sit close to the 1e-6 edge): the shape the value-parallel direct kernel exists for"""
+    from types import SimpleNamespace
+    card = [int(rng.choice([2, 3, 5, 8, 9, 11, 12, 13, 16, 16, 16])) for _ in range(n)]
+    card[0] = 16
+    scopes, tables = [], []
+    for v in range(n):
+        scopes.append([v]); tables.append(np.exp(rng.uniform(-2, 2, card[v])))
+    for _ in range(3 * n):
+        a, b = (int(x) for x in rng.choice(n, 2, replace=False))
+        t = np.exp(rng.uniform(-3, 3, card[a] * card[b]))
+        t[rng.random(t.size) < 0.25] = rng.choice([0.0, 1e-9, 1e-6, 3e-6, 1e-5])
+        scopes.append([a, b]); tables.append(t)
+    fixed = [int(rng.integers(0, c)) if (v % 7 == 3) else -1 for v, c in enumerate(card)]
+    return SimpleNamespace(card=card, scopes=scopes, tables=tables, fixed=fixed)
+
+
+def test_value_parallel_form_equals_chain_per_lane(res_dir):
+    """k_sweep_pw4 (4 lanes per chain, one per block of 4 values; path 6) and the chain-per-lane direct kernel (path 0) are
+    the same process bit for bit: ObjectDetection_13 and random pairwise models with Card 2..16, evidence and floor-heavy
+    tables; quad-unaligned launches; 64-bit chain ids."""
+    rng = np.random.default_rng(77)
+    cases = [(g.Model.NewModelFromFile(os.path.join(res_dir, "ObjectDetection_13.uai")), 320)]
+    cases += [(_gm(_pairwise_big_card_model(rng)), 128) for _ in range(3)]
+    for m, chains in cases:
+        runs = []
+        for form in (2, 1):
+            s = g.HIPChains(m, chains, seed=31, chain_offset=(1 << 36) + 64 * 9, fast_form=form)
+            s.BurnIn(37); s.Advance(101); s.Advance(66)
+            runs.append((s.info()["path"], s.counts(), s.checkpoint()["states"]))
+        assert runs[0][0] == 6 and runs[1][0] == 0
+        assert np.array_equal(runs[0][1], runs[1][1])
+        assert np.array_equal(runs[0][2], runs[1][2])
+        assert int(runs[0][1].sum()) == chains * 167
+
+
 @pytest.mark.parametrize("name,chains,groups", [("Grids_13.uai", 2048, 1), ("Grids_13.uai", 66560, 1), ("Segmentation_11.uai", 1024, 4)])
 def test_strict_mode_memoised_equals_direct(res_dir, name, chains, groups):
     """GR_FLAG_SCAN_PER_CHAIN (every chain draws its own variable, sampler.go:135-174): the memoised strict kernel
