@@ -105,6 +105,7 @@ struct gr_sampler {
     bool par_packed = false;          // step-parallel records use one dword per neighbour
     uint32_t rec_stride = 64;         // bytes per record (128 when a variable has 13..16 neighbours)
     bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
+    bool par_lean = false;            // ... with the lean LDS layout: records always from global memory (large models)
     bool pw4 = false;                 // value-parallel form of the direct path (k_sweep_pw4): pairwise, 8 < Card <= 16
     uint32_t pw4_hist_off = 0, pw4_lds = 0;
     bool strict_fast = false;         // GR_FLAG_SCAN_PER_CHAIN on memoised tables (k_sweep_strict, the 4-lane form's LDS layout)
@@ -257,7 +258,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                 // step-parallel form (4 lanes per chain): wins while the chain-per-lane form leaves SIMDs with
                 // a single wavefront (measured on Grids_13: 4.9e11 vs 4.1e11 updates/s at 65 536 chains,
                 // 5.0e11 vs 6.2e11 at 131 072)
-                par = false;
+                par = false; par_lean = false;
                 const uint32_t form = try_strict_fast ? 2u : o.fast_form; // 0 auto, 1 chain per lane, 2 four lanes per chain
                 if (fast_ok && use_cpt && tl && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && form != 1 &&
                     (form >= 2 || o.n_chains / 64u <= 1536u || !cpl_fast)) {
@@ -272,7 +273,13 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                     par_lds = b2;
                     const bool fits16 = (uint64_t)n_vars * kParStateStride < 65536u && max_mult * 4u < 65536u;
                     par_packed = fits16;
-                    par = b2 <= kLdsBudget && (slots <= 6 || fits16) && (o.n_variants == 1 || cpv % 64u == 0) && (o.n_chains % 64u) == 0;
+                    // Large models (Promedus_17: 916 variables, dv-rel_2: 1 200): state + tables fit, the LDS copy of the records
+                    // does not.  With the records read from global memory (record mode 2) the kernel needs neither that copy nor
+                    // the plan ring: the "lean" layout ends after the tables.  (Without it such models ran the chain-per-lane
+                    // form with one 64-lane block per CU: 125 KB of LDS behind a single wavefront.)
+                    par_lean = b2 > kLdsBudget && par_rec_off <= kLdsBudget && !try_strict_fast && (o.fast_form < 4 || o.fast_form == 6);
+                    if (par_lean) par_lds = par_rec_off;
+                    par = par_lds <= kLdsBudget && (slots <= 6 || fits16) && (o.n_variants == 1 || cpv % 64u == 0) && (o.n_chains % 64u) == 0;
                     if (par) fast = true;
                 }
                 return;
@@ -477,7 +484,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.cpt = d_cpt.p; f.recs = d_recs.p; f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p;
         f.plan_pitch = plan_steps;
         f.rec_stride = rec_stride;
-        f.par_recmode = o.fast_form >= 4 && o.fast_form <= 6 ? o.fast_form - 4u : 99u;
+        f.par_recmode = par_lean ? 2u : o.fast_form >= 4 && o.fast_form <= 6 ? o.fast_form - 4u : 99u;
         if (!d_err.p) {
             d_err.alloc(1);
             hip_check(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), stream), "hipMemset");

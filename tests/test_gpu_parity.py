@@ -212,6 +212,7 @@ def _thresholds_from_device(s, cards):
     ("ObjectDetection_13.uai", False, 64, 41, 0),
     ("Pedigree_11.uai", True, 64, 61, 0),
     ("one.uai", False, 1, 64, 0),
+    ("dv-rel_2.uai", True, 64, 61, 0),   # 1 200 variables: the 4-lane form's lean LDS layout (records from global memory)
     ("Grids_11.uai", False, 128, 97, g.GR_FLAG_SCAN_PER_CHAIN),       # strict mode: per-chain variable draws
     ("ObjectDetection_13.uai", False, 64, 33, g.GR_FLAG_SCAN_PER_CHAIN),
     ("Pedigree_11.uai", True, 70, 45, g.GR_FLAG_SCAN_PER_CHAIN),
