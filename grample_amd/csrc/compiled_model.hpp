@@ -55,7 +55,8 @@ struct VariantImage {
 };
 
 struct CompileLimits {
-    uint32_t max_cpt_words = 28 * 1024; // threshold pool budget (words) for the memoised path
+    uint32_t max_cpt_words = 1u << 20;  // threshold pool budget (words) of one chain group for the memoised path: pools up to
+                                        // ~28 K words are staged in LDS, larger ones (to 4 MB) are read from global memory / L2
     uint32_t max_cpt_neighbours = 16;
 };
 

@@ -102,6 +102,9 @@ struct FastParams {
     uint32_t plan_slots, plan_nfree_max; // k_scan_plan's LDS table: most neighbours of a variable, most selectable variables of a group
     uint32_t strict_state_off;   // k_sweep_strict with 4 waves per block: state regions of waves 1..3
     uint32_t strict_rec_stride;  // k_sweep_strict: record stride in LDS (rec_stride + 16 when it fits: bank spreading)
+    uint32_t par_stride;         // k_sweep_par4: bytes between the state rows of consecutive variables (80, or 64 for very large models)
+    uint32_t tab_global;         // k_sweep_par4: threshold tables too large for LDS -- read from global memory (record word 2 = byte
+                                 // offset inside the group's pool); records from global memory too (record mode 2)
 };
 
 // Arguments of the scan-stream kernels behind gr_advance_chain (k_stop_time, k_ring_halves): one thread per

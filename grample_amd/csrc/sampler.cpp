@@ -74,6 +74,7 @@ struct DevBuf {
 
 constexpr uint32_t kLdsBudget = 160 * 1024;   // LDS per CU on gfx950
 constexpr uint32_t kMaxStepsPerLaunch = 1u << 20; // keeps the u32 wave histograms far from overflow
+constexpr uint64_t kMaxCptWordsTotal = 4ull << 20; // memoised threshold pools of all chain groups together: 16 MB (L2 / MALL resident)
 
 } // namespace
 
@@ -106,6 +107,8 @@ struct gr_sampler {
     uint32_t rec_stride = 64;         // bytes per record (128 when a variable has 13..16 neighbours)
     bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
     bool par_lean = false;            // ... with the lean LDS layout: records always from global memory (large models)
+    uint32_t par_stride = 80;         // ... bytes between the LDS state rows of consecutive variables
+    bool par_tabg = false;            // ... and the threshold tables too (pools that do not fit LDS)
     bool pw4 = false;                 // value-parallel form of the direct path (k_sweep_pw4): pairwise, 8 < Card <= 16
     uint32_t pw4_hist_off = 0, pw4_lds = 0;
     bool strict_fast = false;         // GR_FLAG_SCAN_PER_CHAIN on memoised tables (k_sweep_strict, the 4-lane form's LDS layout)
@@ -188,12 +191,15 @@ void gr_sampler::configure_paths() {
 void gr_sampler::configure_impl(bool try_strict_fast) {
     cpv = o.n_chains / o.n_variants;
     uint32_t views_max = 0, cpt_max = 0;
+    uint64_t cpt_sum = 0;
     bool all_cpt = !(o.flags & GR_FLAG_DIRECT) && (try_strict_fast || !(o.flags & GR_FLAG_SCAN_PER_CHAIN));
     for (const auto &im : image) {
         views_max = std::max<uint32_t>(views_max, (uint32_t)im.views.size());
         cpt_max = std::max<uint32_t>(cpt_max, (im.cpt_words + 3u) & ~3u);
         all_cpt = all_cpt && im.cpt_ok;
+        cpt_sum += (uint64_t)((im.cpt_words + 3u) & ~3u);
     }
+    if (cpt_sum > kMaxCptWordsTotal) all_cpt = false; // (every chain group has its own pool)
     uint32_t plan_off = 0;
     auto layout = [&](uint32_t t, bool use_cpt, bool tl, uint32_t &hist_off, uint32_t &tab_off) -> uint32_t {
         uint32_t b = (uint32_t)n_vars * t;
@@ -239,8 +245,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
     for (int pass = 0; pass < 2; ++pass) { // pass 0: memoised path if allowed, pass 1: direct
         const bool use_cpt = (pass == 0) && all_cpt;
         if (pass == 0 && !use_cpt) continue;
-        for (bool tl : {true, false}) {
-            if (use_cpt && !tl) continue; // memoised tables are only worth it from LDS
+        for (bool tl : {true, false}) { // tables (thresholds or views) staged in LDS, else read from global memory / L2
             for (uint32_t t : cands) {
                 if (o.n_variants > 1 && cpv % t) continue;
                 uint32_t ho, to;
@@ -260,27 +265,34 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                 // 5.0e11 vs 6.2e11 at 131 072)
                 par = false; par_lean = false;
                 const uint32_t form = try_strict_fast ? 2u : o.fast_form; // 0 auto, 1 chain per lane, 2 four lanes per chain
-                if (fast_ok && use_cpt && tl && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && form != 1 &&
+                par_tabg = false;
+                if (fast_ok && use_cpt && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && form != 1 &&
+                    (tl || (!try_strict_fast && (o.fast_form < 4 || o.fast_form == 6))) &&
                     (form >= 2 || o.n_chains / 64u <= 1536u || !cpl_fast)) {
                     uint32_t nfree_max = 0;
                     for (const auto &im : image) nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)im.free_vars.size());
-                    uint32_t b2 = ((uint32_t)n_vars * kParStateStride + 15u) & ~15u;
+                    // 80-byte state rows spread the 4 rows of an access over the LDS banks; a model with more than 6 neighbours per
+                    // variable packs row offsets into 16 bits, so above 819 variables its rows are 64 bytes apart instead
+                    par_stride = (slots > 6 && (uint64_t)n_vars * kParStateStride >= 65536u && !try_strict_fast) ? 64u : kParStateStride;
+                    uint32_t b2 = ((uint32_t)n_vars * par_stride + 15u) & ~15u;
                     par_hist_off = b2; b2 += ((uint32_t)H * 4u + 15u) & ~15u;
-                    par_tab_off = b2; b2 += cpt_max * 4u;
+                    par_tab_off = b2; b2 += tl ? cpt_max * 4u : 0u; // (!tl: thresholds from global memory, k_sweep_par4<.., TABG>)
                     par_rec_off = b2; b2 += nfree_max * rec_stride;
                     par_plan_off = b2; b2 += 4u * 1024u;
                     par_scr_off = b2; b2 += 4u * 64u * 16u;
                     par_lds = b2;
-                    const bool fits16 = (uint64_t)n_vars * kParStateStride < 65536u && max_mult * 4u < 65536u;
+                    const bool fits16 = (uint64_t)n_vars * par_stride < 65536u && max_mult * 4u < 65536u;
                     par_packed = fits16;
                     // Large models (Promedus_17: 916 variables, dv-rel_2: 1 200): state + tables fit, the LDS copy of the records
                     // does not.  With the records read from global memory (record mode 2) the kernel needs neither that copy nor
                     // the plan ring: the "lean" layout ends after the tables.  (Without it such models ran the chain-per-lane
                     // form with one 64-lane block per CU: 125 KB of LDS behind a single wavefront.)
-                    par_lean = b2 > kLdsBudget && par_rec_off <= kLdsBudget && !try_strict_fast && (o.fast_form < 4 || o.fast_form == 6);
+                    par_lean = (!tl || b2 > kLdsBudget) && par_rec_off <= kLdsBudget && !try_strict_fast && (o.fast_form < 4 || o.fast_form == 6);
                     if (par_lean) par_lds = par_rec_off;
+                    par_tabg = !tl;
                     par = par_lds <= kLdsBudget && (slots <= 6 || fits16) && (o.n_variants == 1 || cpv % 64u == 0) && (o.n_chains % 64u) == 0;
                     if (par) fast = true;
+                    else par_tabg = false;
                 }
                 return;
             }
@@ -382,13 +394,13 @@ void gr_sampler::rebuild() {
                     const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
                     const uint32_t nn = (cp[0] >> 8) & 0xffu;
                     uint32_t r[32] = {0};
-                    r[0] = v * kParStateStride;
+                    r[0] = v * par_stride;
                     r[1] = par_hist_off + cp[1] * 4u;
-                    r[2] = par_tab_off + cp[2] * 4u;
+                    r[2] = (par_tabg ? 0u : par_tab_off) + cp[2] * 4u;
                     r[3] = nn;
                     const bool packed = par_packed;
                     for (uint32_t i = 0; i < (packed ? (rec_stride == 128u ? 16u : 12u) : 6u); ++i) {
-                        const uint32_t off = (i < nn ? cp[3 + 2 * i] : v) * kParStateStride, m4 = (i < nn ? cp[4 + 2 * i] : 0u) * 4u;
+                        const uint32_t off = (i < nn ? cp[3 + 2 * i] : v) * par_stride, m4 = (i < nn ? cp[4 + 2 * i] : 0u) * 4u;
                         if (packed) r[4 + i] = off | (m4 << 16);
                         else { r[4 + 2 * i] = off; r[5 + 2 * i] = m4; }
                     }
@@ -475,7 +487,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         T = 256; blocks = (act + 255) / 256;
         generic(n_total);
     };
-    if (!fast) {
+    if (!fast || (par_tabg && cur_log)) { // (the global-table 4-lane form is not built with the draw log)
         generic(updates);
     } else {
         // quad-unaligned head and tail go through the generic kernel (bit-identical streams)
@@ -484,6 +496,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.cpt = d_cpt.p; f.recs = d_recs.p; f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p;
         f.plan_pitch = plan_steps;
         f.rec_stride = rec_stride;
+        f.tab_global = par_tabg ? 1u : 0u;
+        f.par_stride = par_stride;
         f.par_recmode = par_lean ? 2u : o.fast_form >= 4 && o.fast_form <= 6 ? o.fast_form - 4u : 99u;
         if (!d_err.p) {
             d_err.alloc(1);

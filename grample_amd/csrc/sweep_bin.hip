@@ -297,7 +297,8 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
 // commits level 0, and only when the quad has higher levels are the conditionals re-gathered and
 // the next level committed.  Every (chain, step) uses the same Philox word and the same threshold
 // table as in the other kernels: bit-identical results.
-//   state     lds[var * 80 + chain]           (80-byte rows: 4 different rows per access land on different banks)
+//   state     lds[var * 80 + chain]           (80-byte rows: 4 different rows per access land on different banks; 64-byte rows
+//             -- FastParams::par_stride -- for models so large that 80-byte row offsets no longer fit a packed record's 16 bits)
 //   records   staged in LDS, read per lane (4 distinct records per access, broadcast inside a step slot)
 //   lanes     lane = j * 16 + c: a 16-lane LDS lane group / DPP row is one step slot
 //   draws     lane (j, c) computes Philox for quad 4*SQ + j of chain c; two pairs of gfx950 lane swaps transpose
@@ -323,8 +324,9 @@ struct RecL { // a record as per-lane VGPR values
 template <int SLOTS, bool PACKED>
 __device__ __forceinline__ uint32_t comp4(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
-template <int SLOTS, bool PACKED>
-__device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const unsigned char *lds_c, const unsigned char *lds, const uint32_t u) {
+// TABG: the threshold word comes from global memory (tabg + the record's byte offset) instead of LDS
+template <int SLOTS, bool PACKED, bool TABG = false>
+__device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const unsigned char *lds_c, const unsigned char *tabg, const uint32_t u) {
     uint32_t cfg4 = 0;
 #pragma unroll
     for (int i = 0; i < SLOTS; ++i) {
@@ -339,7 +341,8 @@ __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const
         }
         cfg4 += __umul24(m4, (uint32_t)lds_c[off]);
     }
-    const uint32_t T = *lds_at(r.h.z + cfg4); // r.h.z: absolute LDS address (staged records)
+    const uint32_t T = TABG ? *reinterpret_cast<const uint32_t *>(tabg + (r.h.z + cfg4))
+                            : *lds_at(r.h.z + cfg4); // r.h.z: absolute LDS address (staged records)
     return (u >= T) ? 1u : 0u;
 }
 
@@ -369,7 +372,10 @@ __device__ __forceinline__ uint32_t table_l(const RecL<SLOTS, PACKED> &r, const 
 // RECMODE 2: the records come from global memory instead (vector loads through L1, prefetched one iteration ahead):
 // the LDS pipe is this form's tightest resource and the record reads are 14 of its 48 cycles per step, while the
 // vector-memory path is otherwise idle.
-template <int SLOTS, bool PACKED, int MODE, int RECMODE> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
+// TABG (with RECMODE 2 only): threshold pools too large for LDS (Pedigree without evidence: 36 K words, dv-rel_3: 512 K) are read
+// from global memory -- one dependent L2 access per step instead of an LDS one, hidden by the block's other wavefronts; still
+// an order of magnitude cheaper than evaluating the conditional from the factor tables.
+template <int SLOTS, bool PACKED, int MODE, int RECMODE, bool TABG = false> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
 __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     constexpr bool COUNT = MODE != 0, LOG = MODE == 2;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -385,7 +391,8 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         const uint32_t n4 = (vd.cpt_len + 3u) >> 2;
         const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
         uint4 *dst = reinterpret_cast<uint4 *>(lds + p.par_tab_off);
-        for (uint32_t i = tid; i < n4; i += 256) dst[i] = src[i];
+        if constexpr (!TABG)
+            for (uint32_t i = tid; i < n4; i += 256) dst[i] = src[i];
         const uint4 *rs = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.recs_par) + (size_t)vd.rec_base * p.rec_stride);
         uint4 *rd = reinterpret_cast<uint4 *>(lds + p.par_rec_off);
         const uint32_t per = p.rec_stride / 16u, base = lds_addr_of(lds);
@@ -395,7 +402,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
                 if (i % per == 0) { q.y += base; q.z += base; } // histogram and table offsets -> absolute LDS addresses
                 rd[i] = q;
             }
-        for (uint32_t v = j; v < p.n_vars; v += 4) lds[v * kParStride + cb] = p.state[(size_t)v * p.pitch + chain];
+        for (uint32_t v = j; v < p.n_vars; v += 4) lds[v * p.par_stride + cb] = p.state[(size_t)v * p.pitch + chain];
         uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
         for (uint32_t i = tid; i < p.H; i += 256) h[i] = 0;
     }
@@ -405,6 +412,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     const uint64_t q0 = (((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2;
     const uint32_t nq = p.n_steps >> 2; // multiple of 4
     const unsigned char *lds_c = lds + cb;
+    const unsigned char *tabp = TABG ? reinterpret_cast<const unsigned char *>(p.cpt + vd.cpt_base) : lds; // where sample_l finds the thresholds
     const uint32_t rec_bias = p.par_rec_off - vd.rec_base * p.rec_stride;
 
     // the block's scan plan (all 4 waves walk the same plan), staged per wave through an LDS ring
@@ -545,18 +553,18 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             const uint32_t lv = (pw[k] >> 1) & 3u;
             const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
             const uint32_t sidx = (g0 + k) * 4u + j;
-            uint32_t val = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+            uint32_t val = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]);
             store(r, val, lv == 0, sidx);
             if (maxlv >= 1) { // the quad has steps that do not commute: re-gather after the lower levels committed
-                uint32_t v2 = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+                uint32_t v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]);
                 store(r, v2, lv == 1, sidx);
                 val = lv == 1 ? v2 : val;
                 if (maxlv >= 2) {
-                    v2 = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+                    v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]);
                     store(r, v2, lv == 2, sidx);
                     val = lv == 2 ? v2 : val;
                     if (maxlv >= 3) {
-                        v2 = sample_l<SLOTS, PACKED>(r, lds_c, lds, U[k]);
+                        v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]);
                         store(r, v2, lv == 3, sidx);
                         val = lv == 3 ? v2 : val;
                     }
@@ -566,7 +574,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         }
     }
 
-    for (uint32_t v = j; v < p.n_vars; v += 4) p.state[(size_t)v * p.pitch + chain] = lds[v * kParStride + cb];
+    for (uint32_t v = j; v < p.n_vars; v += 4) p.state[(size_t)v * p.pitch + chain] = lds[v * p.par_stride + cb];
     if constexpr (COUNT) {
         __syncthreads();
         const uint32_t *h = reinterpret_cast<const uint32_t *>(lds + p.par_hist_off);
@@ -708,6 +716,8 @@ static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t ld
     // where the records come from (p.par_recmode: 0..2 forced, else by occupancy): with fewer than 3 wavefronts per SIMD
     // (256 CUs x 4 SIMDs, 4 wavefronts per block) the kernel is latency-bound -> LDS records fetched together; with more it
     // sits on the LDS pipe -> records from global memory, prefetched an iteration ahead
+    if (p.tab_global) // thresholds from global memory: record mode 2, no draw log (the host runs logged windows on the generic kernel)
+        return p.log ? hipErrorInvalidValue : !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 2, true>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 2, true>);
     const int rm = p.par_recmode <= 2u ? (int)p.par_recmode : (blocks * 4u < 3u * 1024u ? 1 : 2);
     if (rm == 2) return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 2>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 2>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 2>);
     if (rm == 1) return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 1>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 1>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 1>);

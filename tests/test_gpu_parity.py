@@ -213,6 +213,8 @@ def _thresholds_from_device(s, cards):
     ("Pedigree_11.uai", True, 64, 61, 0),
     ("one.uai", False, 1, 64, 0),
     ("dv-rel_2.uai", True, 64, 61, 0),   # 1 200 variables: the 4-lane form's lean LDS layout (records from global memory)
+    ("dv-rel_3.uai", False, 64, 45, 0),  # 512 K threshold words: the 4-lane form with tables read from global memory
+    ("Pedigree_11.uai", False, 64, 33, 0),  # 36 K threshold words, Card 3: generic memoised kernel, tables from global memory
     ("Grids_11.uai", False, 128, 97, g.GR_FLAG_SCAN_PER_CHAIN),       # strict mode: per-chain variable draws
     ("ObjectDetection_13.uai", False, 64, 33, g.GR_FLAG_SCAN_PER_CHAIN),
     ("Pedigree_11.uai", True, 70, 45, g.GR_FLAG_SCAN_PER_CHAIN),
@@ -269,6 +271,21 @@ def test_all_kernel_forms_agree_bit_for_bit(res_dir):
     for k in (1, 2, 3, 34, 35, 36):  # 34..36: the 4-lane form's three record sources
         assert np.array_equal(runs[0][1], runs[k][1]), k
         assert np.array_equal(runs[0][2], runs[k][2]), k
+
+
+@pytest.mark.parametrize("name,ev,path", [("dv-rel_3.uai", False, 3), ("dv-rel_3.uai", True, 3), ("Pedigree_11.uai", False, 1)])
+def test_global_threshold_tables_equal_direct(res_dir, name, ev, path):
+    """Memoised threshold pools too large for LDS are read from global memory (4-lane form for binary models, generic
+    memoised kernel otherwise): same process as the direct path, bit for bit."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name), ev)
+    out = []
+    for flags in (0, g.GR_FLAG_DIRECT):
+        s = g.HIPChains(m, 1024, seed=3, flags=flags, chain_offset=64)
+        s.BurnIn(50); s.Advance(203); s.Advance(64)
+        i = s.info()
+        out.append((i["path"], i["tables_in_lds"], s.counts(), s.checkpoint()["states"]))
+    assert (out[0][0], out[0][1]) == (path, 0) and out[1][0] == 0
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
 
 
 def _pairwise_big_card_model(rng, n=24):
