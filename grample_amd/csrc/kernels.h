@@ -25,8 +25,8 @@ struct CollapseArgs {
 
 constexpr int kMaxSupportedCard = 64; // largest Card the register-resident conditional handles
 
-hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, bool per_chain, uint32_t blocks, uint32_t threads,
-                        uint32_t lds_bytes, hipStream_t s);
+hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, bool per_chain, bool state_global, uint32_t blocks,
+                        uint32_t threads, uint32_t lds_bytes, hipStream_t s);
 hipError_t launch_init_state(unsigned char *state, const int32_t *card, const int32_t *fixed, uint32_t n_vars, uint32_t pitch,
                              uint32_t chain_begin, uint32_t chain_end, uint64_t chain_offset, uint64_t seed, uint32_t epoch,
                              hipStream_t s);

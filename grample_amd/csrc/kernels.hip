@@ -150,7 +150,10 @@ __device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, 
 // LOG: write the draw log of gr_advance_chain (only instantiated for the direct back-end, tables from global memory:
 // every back-end draws the same values, and keeping the log code out of the other instantiations keeps them compact --
 // with it inlined everywhere ObjectDetection_13 ran 17 % slower)
-template <int MAXC, bool CPT, bool TAB_LDS, bool PW, bool PC, bool LOG = false>
+// STG: the chain state stays in global memory as it is laid out there -- state[var][chain], one coalesced 64-byte row per
+// wavefront and variable -- instead of being staged in LDS: for models whose state does not fit LDS (n_vars * 64 B per
+// wavefront > 160 KiB) and as GR_FLAG_STATE_GLOBAL for cross-checks.  Same arithmetic, same order: bit-identical results.
+template <int MAXC, bool CPT, bool TAB_LDS, bool PW, bool PC, bool LOG = false, bool STG = false>
 __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t T = blockDim.x;
@@ -179,7 +182,9 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
         tab_f = p.views + vd.views_base;
         tab_u = p.cpt + vd.cpt_base;
     }
-    for (uint32_t v = 0; v < p.n_vars; ++v) st[v * T] = active ? p.state[(size_t)v * p.pitch + chain] : (unsigned char)0;
+    if constexpr (!STG)
+        for (uint32_t v = 0; v < p.n_vars; ++v) st[v * T] = active ? p.state[(size_t)v * p.pitch + chain] : (unsigned char)0;
+    unsigned char *gst = p.state + chain; // STG: this chain's column of the global state (inactive lanes stay inside the row pitch)
     for (uint32_t i = lane; i < p.H; i += 64) hist[i] = 0;
     __syncthreads();
 
@@ -195,7 +200,10 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     const bool seq = p.sequential != 0;
     const bool counting = p.counting != 0;
 
-    auto get = [&](uint32_t u) -> uint32_t { return (uint32_t)st[u * T]; };
+    auto get = [&](uint32_t u) -> uint32_t {
+        if constexpr (STG) return (uint32_t)gst[(size_t)u * p.pitch];
+        else return (uint32_t)st[u * T];
+    };
 
     // new value of variable v (program pg) given the current state and the draw u
     auto sample = [&](const uint32_t *pg, const uint32_t u, const uint32_t p0, const uint32_t p1, const uint32_t p2,
@@ -236,7 +244,8 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
         }
     auto commit = [&](const uint32_t v, const uint32_t *pg, const uint32_t val, const uint32_t sidx) {
         if (LOG && sidx >= lim) return; // the group has finished its AdvanceChain: state, counts and log stay as they are
-        st[v * T] = (unsigned char)val;
+        if constexpr (STG) { if (active) gst[(size_t)v * p.pitch] = (unsigned char)val; }
+        else st[v * T] = (unsigned char)val;
         if (counting) {
             const uint32_t C = pg[0] & 0xffu, ho = pg[1];
             if (!PC && C == 2) {
@@ -309,8 +318,9 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     }
 
     // flush: state back to HBM (coalesced rows), wave-private histograms -> global counts
-    for (uint32_t vv = 0; vv < p.n_vars; ++vv)
-        if (active) p.state[(size_t)vv * p.pitch + chain] = st[vv * T];
+    if constexpr (!STG)
+        for (uint32_t vv = 0; vv < p.n_vars; ++vv)
+            if (active) p.state[(size_t)vv * p.pitch + chain] = st[vv * T];
     if (counting) {
         unsigned long long *gc = p.counts + (size_t)variant * p.H;
         for (uint32_t i = lane; i < p.H; i += 64) {
@@ -595,20 +605,25 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
         else { constexpr int MC = 64; __VA_ARGS__; }               \
     } while (0)
 
-template <int MC, bool CPT, bool TL, bool PW, bool PC = false, bool LOG = false>
+template <int MC, bool CPT, bool TL, bool PW, bool PC = false, bool LOG = false, bool STG = false>
 static hipError_t launch_sweep_t(const SweepParams &p, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<MC, CPT, TL, PW, PC, LOG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<MC, CPT, TL, PW, PC, LOG, STG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sweep<MC, CPT, TL, PW, PC, LOG>), dim3(blocks), dim3(threads), lds, s, p);
+    hipLaunchKernelGGL((k_sweep<MC, CPT, TL, PW, PC, LOG, STG>), dim3(blocks), dim3(threads), lds, s, p);
     return hipGetLastError();
 }
 
-hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, bool per_chain, uint32_t blocks,
-                        uint32_t threads, uint32_t lds_bytes, hipStream_t s) {
+hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, bool per_chain, bool state_global,
+                        uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t s) {
     hipError_t e = hipSuccess;
     GR_DISPATCH_MAXC(max_card, {
-        if (p.log) e = (per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, false, true>(p, blocks, threads, lds_bytes, s);
+        if (state_global) // state in global memory: tables from global memory too; no strict mode, no draw log
+            e = (p.log || per_chain || tab_lds) ? hipErrorInvalidValue
+                : cpt ? launch_sweep_t<MC, true, false, false, false, false, true>(p, blocks, threads, lds_bytes, s)
+                : pairwise ? launch_sweep_t<MC, false, false, true, false, false, true>(p, blocks, threads, lds_bytes, s)
+                           : launch_sweep_t<MC, false, false, false, false, false, true>(p, blocks, threads, lds_bytes, s);
+        else if (p.log) e = (per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, false, true>(p, blocks, threads, lds_bytes, s);
         else if (per_chain) e = tab_lds ? launch_sweep_t<MC, false, true, false, true>(p, blocks, threads, lds_bytes, s)
                                    : launch_sweep_t<MC, false, false, false, true>(p, blocks, threads, lds_bytes, s);
         else if (cpt) e = tab_lds ? launch_sweep_t<MC, true, true, false>(p, blocks, threads, lds_bytes, s)

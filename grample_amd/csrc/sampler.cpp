@@ -109,6 +109,7 @@ struct gr_sampler {
     bool par_lean = false;            // ... with the lean LDS layout: records always from global memory (large models)
     uint32_t par_stride = 80;         // ... bytes between the LDS state rows of consecutive variables
     bool par_tabg = false;            // ... and the threshold tables too (pools that do not fit LDS)
+    bool stg = false;                 // chain state stays in global memory (k_sweep<.., STG>): models whose state does not fit LDS
     bool pw4 = false;                 // value-parallel form of the direct path (k_sweep_pw4): pairwise, 8 < Card <= 16
     uint32_t pw4_hist_off = 0, pw4_lds = 0;
     bool strict_fast = false;         // GR_FLAG_SCAN_PER_CHAIN on memoised tables (k_sweep_strict, the 4-lane form's LDS layout)
@@ -164,7 +165,7 @@ void gr_sampler::configure() {
     pw4 = false;
     bool all_pw = true;
     for (const auto &im : image) all_pw = all_pw && im.pairwise;
-    if (all_pw && !fast && !cpt && max_card > 8 && max_card <= 16 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE)) &&
+    if (all_pw && !fast && !cpt && !stg && max_card > 8 && max_card <= 16 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE)) &&
         o.fast_form != 1 && (o.n_chains % 64u) == 0 && (o.n_variants == 1 || cpv % 64u == 0) && !o.block_threads) {
         pw4_hist_off = ((uint32_t)n_vars * 64u + 15u) & ~15u;
         pw4_lds = pw4_hist_off + 4u * (uint32_t)H * 4u;
@@ -214,6 +215,23 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
         if (use_cpt && tl) b += (t / 64u) * 1024u; // fast path: per-wave scan-plan ring (2 x 32 quads x 16 B)
         return b;
     };
+    // State in global memory: forced by flag, or the fallback when no LDS layout fits (below).  Generic kernel only: thresholds /
+    // views from global memory, wave-private histograms in LDS.
+    stg = false;
+    auto state_global = [&]() {
+        if (o.flags & GR_FLAG_SCAN_PER_CHAIN) throw Error(GR_E_UNSUPPORTED, "strict per-chain scan needs the chain state in LDS (model too large, or GR_FLAG_STATE_GLOBAL)");
+        for (uint32_t t : {256u, 64u}) {
+            if (o.n_variants > 1 && cpv % t) continue;
+            const uint32_t b = (t / 64u) * (uint32_t)H * 4u;
+            if (b > kLdsBudget) continue;
+            stg = true; fast = false; par = false; par_lean = false; par_tabg = false;
+            T = t; lds = b; lds_hist_off = 0; lds_tab_off = b; lds_plan_off = b; cpt = all_cpt; tab_lds = false;
+            blocks = (o.n_chains + T - 1) / T;
+            return;
+        }
+        throw Error(GR_E_UNSUPPORTED, "model too large: the per-wavefront histogram (sum of Card * 4 bytes) does not fit LDS");
+    };
+    if (o.flags & GR_FLAG_STATE_GLOBAL) { state_global(); return; }
     // fast path (sweep_bin.hip): every selectable variable binary, memoised tables, whole wavefronts
     bool fast_ok = all_cpt && !(o.flags & GR_FLAG_SEQUENTIAL) && (o.n_chains % 64u) == 0 && n_vars < 65536 && H < 16384;
     int slots = 0;
@@ -282,7 +300,8 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                     par_scr_off = b2; b2 += 4u * 64u * 16u;
                     par_lds = b2;
                     const bool fits16 = (uint64_t)n_vars * par_stride < 65536u && max_mult * 4u < 65536u;
-                    par_packed = fits16;
+                    par_packed = fits16; // (unpacked records -- fewer VALU unpack instructions, 48 instead of 32 bytes fetched per
+                                         // step -- measured 27 % SLOWER on Grids_13 at 65 536 chains: the record fetch is a co-limiter)
                     // Large models (Promedus_17: 916 variables, dv-rel_2: 1 200): state + tables fit, the LDS copy of the records
                     // does not.  With the records read from global memory (record mode 2) the kernel needs neither that copy nor
                     // the plan ring: the "lean" layout ends after the tables.  (Without it such models ran the chain-per-lane
@@ -298,7 +317,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
             }
         }
     }
-    throw Error(GR_E_UNSUPPORTED, "model does not fit the LDS-resident chain-state layout (n_vars * 64 bytes > 160 KiB)");
+    state_global(); // no LDS layout holds the chain state (n_vars * 64 bytes > 160 KiB): leave it in global memory
 }
 
 // Concatenate the per-group images into the device pools and (re)build the
@@ -469,7 +488,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 hip_check(launch_sweep_pw4(p, act / 64u, pw4_lds, stream), "k_sweep_pw4 launch");
                 p.lds_hist_off = lds_hist_off;
             } else
-            hip_check(launch_sweep(p, max_card, cpt && !plain, tab_lds && !plain, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0,
+            hip_check(launch_sweep(p, max_card, cpt && !plain, tab_lds && !plain, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, stg,
                                    (act + T - 1) / T, T, lds, stream), "k_sweep launch");
             step += n;
             left -= n;
@@ -584,7 +603,7 @@ void gr_sampler::burn_group(uint32_t group, uint32_t updates) {
     p.n_steps = updates; p.counting = 0; p.sequential = 0;
     p.lds_hist_off = lds_hist_off; p.lds_tab_off = lds_tab_off;
     const uint32_t t = std::min(T, 256u);
-    hip_check(launch_sweep(p, max_card, cpt && !strict_fast, tab_lds && !strict_fast, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, (cpv + t - 1) / t, t, lds, stream),
+    hip_check(launch_sweep(p, max_card, cpt && !strict_fast, tab_lds && !strict_fast, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, stg, (cpv + t - 1) / t, t, lds, stream),
               "k_sweep launch (group burn-in)");
     sync();
 }
@@ -1196,6 +1215,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         if (s->o.flags & GR_FLAG_SCAN_PER_CHAIN) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain is not available in strict per-chain scan mode");
         s->use();
         if (s->dirty) s->rebuild();
+        if (s->stg) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain needs the chain state in LDS (model too large, or GR_FLAG_STATE_GLOBAL): use gr_advance_window");
         const uint32_t act = s->active_chains();
         if (act % 64u) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain needs a multiple of 64 chains");
         const uint32_t n_groups = act / 64u;
@@ -1475,7 +1495,7 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         if (!s || !out || out->struct_size != sizeof(gr_sampler_info)) throw Error(GR_E_INVALID, "bad gr_sampler_info");
         if (s->dirty) { s->use(); s->configure(); }
         out->block_threads = s->T; out->n_blocks = s->blocks; out->lds_bytes = s->lds;
-        out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->cpt ? 1u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
+        out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

@@ -107,6 +107,10 @@ int gr_error_suite(int32_t n_vars, const int32_t *card, const int32_t *fixed1, c
                                             draw inside a 64-chain group (same per-chain law).  About 1.6x slower on binary
                                             memoised models (k_sweep_strict), 20x on the direct path. */
 
+#define GR_FLAG_STATE_GLOBAL (1u << 4)  /* keep the chain state in global memory (one coalesced row per wavefront and variable) instead of
+                                            staging it in LDS: chosen automatically for models whose state does not fit LDS
+                                            (n_vars * 64 B > 160 KiB per wavefront); as a flag it forces that kernel (cross-checks) */
+
 typedef struct gr_sampler_opts {
     uint32_t struct_size;    /* = sizeof(gr_sampler_opts) */
     uint32_t n_chains;       /* chains on this device */
@@ -217,7 +221,8 @@ typedef struct gr_sampler_info {
     uint32_t n_blocks;
     uint32_t lds_bytes;
     uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path), 3 = same, 4 lanes per chain, 5 = strict per-chain scan on memoised tables,
-                               6 = direct conditional, value-parallel (4 lanes per chain, pairwise models with 8 < Card <= 16) */
+                               6 = direct conditional, value-parallel (4 lanes per chain, pairwise models with 8 < Card <= 16);
+                               + 16 when the chain state stays in global memory (paths 0 and 1 only) */
     uint32_t max_card;
     uint32_t tables_in_lds;
     uint32_t n_launches_last;

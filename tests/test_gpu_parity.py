@@ -213,6 +213,9 @@ def _thresholds_from_device(s, cards):
     ("Pedigree_11.uai", True, 64, 61, 0),
     ("one.uai", False, 1, 64, 0),
     ("dv-rel_2.uai", True, 64, 61, 0),   # 1 200 variables: the 4-lane form's lean LDS layout (records from global memory)
+    ("Grids_11.uai", False, 128, 75, g.GR_FLAG_STATE_GLOBAL),           # chain state left in global memory, memoised tables
+    ("ObjectDetection_13.uai", False, 70, 29, g.GR_FLAG_STATE_GLOBAL),  # ... direct pairwise path, ragged wavefront
+    ("Pedigree_11.uai", True, 64, 37, g.GR_FLAG_STATE_GLOBAL | g.GR_FLAG_DIRECT),  # ... direct generic path, evidence
     ("dv-rel_3.uai", False, 64, 45, 0),  # 512 K threshold words: the 4-lane form with tables read from global memory
     ("Pedigree_11.uai", False, 64, 33, 0),  # 36 K threshold words, Card 3: generic memoised kernel, tables from global memory
     ("Grids_11.uai", False, 128, 97, g.GR_FLAG_SCAN_PER_CHAIN),       # strict mode: per-chain variable draws
@@ -286,6 +289,34 @@ def test_global_threshold_tables_equal_direct(res_dir, name, ev, path):
         out.append((i["path"], i["tables_in_lds"], s.counts(), s.checkpoint()["states"]))
     assert (out[0][0], out[0][1]) == (path, 0) and out[1][0] == 0
     assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+
+
+def test_model_larger_than_lds_runs_from_global_state():
+    """A 60 x 60 binary grid (3 600 variables: 225 KiB of state per 64-chain wavefront, more than the 160 KiB of LDS) is not
+    refused: the sampler leaves the chain state in global memory (path 17 = memoised + global state) and the numpy
+    emulator replays it bit for bit."""
+    from types import SimpleNamespace
+    rng = np.random.default_rng(5)
+    L = 60
+    n = L * L
+    scopes, tables = [], []
+    for v in range(n):
+        scopes.append([v]); tables.append(np.exp(rng.uniform(-1, 1, 2)))
+        r, c = divmod(v, L)
+        if c + 1 < L:
+            scopes.append([v, v + 1]); tables.append(np.exp(rng.uniform(-1.5, 1.5, 4)))
+        if r + 1 < L:
+            scopes.append([v, v + L]); tables.append(np.exp(rng.uniform(-1.5, 1.5, 4)))
+    pm = SimpleNamespace(card=[2] * n, scopes=scopes, tables=tables, fixed=[-1] * n)
+    s = g.HIPChains(_gm(pm), 128, seed=8)
+    assert s.info()["path"] == 17
+    em = Emulator(pm.card, pm.fixed, list(range(n)), _thresholds_from_device(s, pm.card), 128, 8)
+    s.BurnIn(9); em.run(9, False)
+    s.Advance(150); em.run(150, True)
+    assert np.array_equal(s.counts()[0], em.counts)
+    assert np.array_equal(s.checkpoint()["states"].astype(np.int64), em.state)
+    with pytest.raises(g.GrError):
+        s.AdvanceChain(4)  # the draw log needs the LDS-state kernel
 
 
 def _pairwise_big_card_model(rng, n=24):
