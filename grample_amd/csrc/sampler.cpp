@@ -286,7 +286,9 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                 par_tabg = false;
                 if (fast_ok && use_cpt && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && form != 1 &&
                     (tl || (!try_strict_fast && (o.fast_form < 4 || o.fast_form == 6))) &&
-                    (form >= 2 || o.n_chains / 64u <= 1536u || !cpl_fast)) {
+                    (form >= 2 || o.n_chains / 64u <= 1536u || !cpl_fast || (kLdsBudget / lds) * (T / 64u) < 8u)) {
+                    // (last clause: a chain-per-lane block whose LDS footprint leaves a CU fewer than 8 wavefronts -- large models,
+                    // Promedus_17: 125 KB behind ONE wavefront -- loses to the 4-lane form at any chain count: 6.8e10 vs 1.1e11)
                     uint32_t nfree_max = 0;
                     for (const auto &im : image) nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)im.free_vars.size());
                     // 80-byte state rows spread the 4 rows of an access over the LDS banks; a model with more than 6 neighbours per
@@ -313,6 +315,12 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                     if (par) fast = true;
                     else par_tabg = false;
                 }
+                // direct path, LDS-resident state, but the footprint keeps most wavefronts waiting for a CU (Alchemy_11 at
+                // 131 072 chains: 108 KB per 128-lane block = 512 resident wavefronts for 2 048): leave the state in global
+                // memory instead (2.3e10 -> 3.9e10 updates/s there; slower whenever the LDS form can keep the chip full)
+                if (!fast && !use_cpt && !try_strict_fast && !(o.flags & GR_FLAG_SCAN_PER_CHAIN) && !o.block_threads &&
+                    (uint64_t)(o.n_chains / 64u) > 2ull * (kLdsBudget / lds) * (T / 64u) * 256u)
+                    state_global();
                 return;
             }
         }
