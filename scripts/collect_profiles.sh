@@ -1,0 +1,24 @@
+#!/bin/bash
+# Round-2 measurement pass on the GPU box: bench line, rocprofv3 kernel stats of the same command, and the PMC passes
+# (separate runs, --pmc with --kernel-trace only) that bench.py's `traffic` / `limiter` fields come from.
+# Everything lands under gpurun_out/r02/; scripts/store_profiles.py copies the summaries into profiles/.
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/r02
+mkdir -p $O
+python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || exit 1
+echo "bench done"; tail -c 600 $O/bench.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
+echo "stats done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err || exit 1
+echo "hbm pmc done"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_sqA -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_sqA.err || exit 1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH --kernel-trace --output-format csv -d $O/pmc_sqB -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_sqB.err || exit 1
+echo "sq pmc done"
+python3 $R/scripts/bench_configs.py > $O/configs.jsonl 2> $O/configs.err || exit 1
+echo "configs done"
+python3 $R/scripts/dev_time.py > $O/dev_time.txt 2>&1
+python3 $R/scripts/dev_od.py > $O/dev_od.txt 2>&1
+python3 $R/scripts/dev_all_models.py 32768 > $O/all_models_32768.txt 2>&1
+echo "all done"

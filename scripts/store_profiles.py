@@ -1,49 +1,72 @@
 #!/usr/bin/env python3
-"""Copies the measurement files of the last gpurun collection pass from gpurun_out/ into profiles/ (round tag r01_f) and
-recomputes profiles/hbm_traffic.json (per-launch HBM bytes of the dominant kernel, corrected as MI355X_MICROARCH.md says:
-KiB units, FETCH_SIZE doubled on gfx950).  bench.py reads `bytes_per_launch` from it, so run bench.py again afterwards."""
+"""Copies the measurement files of the last `scripts/collect_profiles.sh` pass (gpurun_out/<tag>/) into profiles/ under the
+round tag and recomputes profiles/hbm_traffic.json: per-launch HBM bytes of the dominant kernel, corrected as
+MI355X_MICROARCH.md says (KiB units, FETCH_SIZE doubled on gfx950), and its VALU instructions per 64 updates.
+bench.py reads `bytes_per_launch` and `valu_inst_per_64_updates` from that file, so run bench.py again afterwards."""
 import csv
 import json
 import os
 import shutil
+import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
-KERN = "k_sweep_par4<4, true, 1, 2>"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+G, P = os.path.join(ROOT, "gpurun_out", TAG), os.path.join(ROOT, "profiles")
+KERN = "k_sweep_par4<4, true, 1, 2, false>"
+UPD_PER_LAUNCH = 50000 * 65536  # a bench step (100 000 updates per chain) = 2 launches
+
+
+def kernel_rows(path, keep="gr::"):
+    rows = list(csv.reader(open(path)))
+    ki = rows[0].index("Kernel_Name")
+    return [rows[0]] + [r for r in rows[1:] if keep in r[ki]]
 
 
 def main():
-    shutil.copy(os.path.join(G, "configs.jsonl"), os.path.join(P, "r01_configs.jsonl"))
-    shutil.copy(os.path.join(G, "f_bench_under_rocprof.json"), os.path.join(P, "r01_f_bench_under_rocprof.json"))
-    shutil.copy(os.path.join(G, "prof_f", "run_kernel_stats.csv"), os.path.join(P, "r01_f_kernel_stats.csv"))
-    shutil.copy(os.path.join(G, "dev_time.log"), os.path.join(P, "r01_f_dev_time.txt"))
-    for tag, src in (("fetch", "pmc_f_fetch"), ("write", "pmc_f_write")):
-        rows = list(csv.reader(open(os.path.join(G, src, "run_counter_collection.csv"))))
-        ki = rows[0].index("Kernel_Name")
-        keep = [rows[0]] + [r for r in rows[1:] if "gr::" in r[ki]]
-        csv.writer(open(os.path.join(P, f"r01_f_pmc_{tag}_size.csv"), "w", newline="")).writerows(keep)
+    for src, dst in (("bench.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("configs.jsonl", "configs.jsonl"),
+                     ("stats/run_kernel_stats.csv", "kernel_stats.csv"), ("dev_time.txt", "dev_time.txt"), ("dev_od.txt", "dev_od.txt"),
+                     ("all_models_32768.txt", "all_models_32768.txt")):
+        if os.path.exists(os.path.join(G, src)):
+            shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{dst}"))
+    for tag in ("fetch", "write", "sqA", "sqB"):
+        src = os.path.join(G, f"pmc_{tag}", "run_counter_collection.csv")
+        if os.path.exists(src):
+            csv.writer(open(os.path.join(P, f"{TAG}_pmc_{tag}.csv"), "w", newline="")).writerows(kernel_rows(src))
+
+    def rows(tag, ctr, kern):
+        return [r for r in csv.DictReader(open(os.path.join(P, f"{TAG}_pmc_{tag}.csv"))) if r["Counter_Name"] == ctr and kern in r["Kernel_Name"]]
 
     def vals(tag, ctr, kern):
-        return [float(r["Counter_Value"]) for r in csv.DictReader(open(os.path.join(P, f"r01_f_pmc_{tag}_size.csv")))
-                if r["Counter_Name"] == ctr and kern in r["Kernel_Name"]]
+        return [float(r["Counter_Value"]) for r in rows(tag, ctr, kern)]
 
     f, w, pw = vals("fetch", "FETCH_SIZE", KERN), vals("write", "WRITE_SIZE", KERN), vals("write", "WRITE_SIZE", "k_scan_plan")
-    ks = {r["Name"]: r for r in csv.DictReader(open(os.path.join(P, "r01_f_kernel_stats.csv")))}
+    ks = {r["Name"]: r for r in csv.DictReader(open(os.path.join(P, f"{TAG}_kernel_stats.csv")))}
     sw = [r for k, r in ks.items() if KERN in k][0]
     sp = [r for k, r in ks.items() if "k_scan_plan" in k][0]
     fm, wm = sum(f) / len(f), sum(w) / len(w)
-    d = json.load(open(os.path.join(P, "hbm_traffic.json")))
-    d["kernel"] = f"gr::{KERN} (binary memoised path, 4 lanes per chain, counting) -- the dominant kernel of bench.py"
-    d["fetch_size_kb_mean"], d["write_size_kb_mean"] = round(fm, 1), round(wm, 1)
-    d["bytes_per_launch"] = int(2 * fm * 1024 + wm * 1024)
-    d["scan_plan_kernel"]["write_size_kb_mean"] = round(sum(pw) / len(pw), 1)
-    d["scan_plan_kernel"]["avg_ns"] = int(float(sp["AverageNs"]))
-    d["avg_launch_ns"] = {KERN: int(float(sw["AverageNs"])), "k_scan_plan": int(float(sp["AverageNs"]))}
-    upd = 50000 * 65536
-    d["note"] = ("real HBM traffic of the sweep = scan plan read + chain state in/out (2 x 6.55 MB) + 200 counters per block: "
-                 "%.3f B per update against 53 B algorithmic; tables, records, state and histograms stay in LDS for the whole launch" % (d["bytes_per_launch"] / upd))
+    # VALU instructions per 64 updates: one bench step = two sweep launches = 100 000 updates on each of 65 536 chains
+    valu = vals("sqA", "SQ_INSTS_VALU", KERN)
+    per64 = sum(valu[-2:]) / (100000.0 * 65536.0 / 64.0)
+    d = {
+        "round": int(TAG[1:]),
+        "kernel": f"gr::{KERN} (binary memoised path, 4 lanes per chain, counting) -- the dominant kernel of bench.py",
+        "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE; SQ_* in two more passes) --kernel-trace --output-format csv -- python3 bench.py "
+                   "--steps 5 --warmup 1 --no-cpu-baseline ; kernel durations from rocprofv3 --kernel-trace --stats of the same command (scripts/collect_profiles.sh)",
+        "launch_shape": "a bench step (100000 updates per chain) = 1 launch of 65536 updates + 1 of 34464: mean 50000 updates x 65536 chains = 3.28e9 updates per launch",
+        "fetch_size_kb_mean": round(fm, 1), "write_size_kb_mean": round(wm, 1),
+        "correction": "MI355X_MICROARCH.md HBM section: counters are in KiB; on gfx950 FETCH_SIZE reports 1/2 of wide coalesced read bytes -> doubled; WRITE_SIZE as is",
+        "bytes_per_launch": int(2 * fm * 1024 + wm * 1024),
+        "algorithmic_bytes_per_launch": int(53.0 * UPD_PER_LAUNCH),
+        "scan_plan_kernel": {"write_size_kb_mean": round(sum(pw) / len(pw), 1), "avg_ns": int(float(sp["AverageNs"]))},
+        "avg_launch_ns": {KERN: int(float(sw["AverageNs"])), "k_scan_plan": int(float(sp["AverageNs"]))},
+        "valu_inst_per_64_updates": round(per64, 2),
+        "valu_note": "SQ_INSTS_VALU of one bench step's two sweep launches / (6.5536e9 updates / 64): VALU wave-instructions per 64 updates",
+        "files": sorted(x for x in os.listdir(P) if x.startswith(TAG + "_")),
+    }
+    d["note"] = ("real HBM traffic of the sweep = scan plan read + chain state in/out + counters: %.3f B per update against 53 B algorithmic; "
+                 "tables, records, state and histograms stay in LDS for the whole launch" % (d["bytes_per_launch"] / UPD_PER_LAUNCH))
     json.dump(d, open(os.path.join(P, "hbm_traffic.json"), "w"), indent=2)
-    print(d["bytes_per_launch"], d["avg_launch_ns"])
+    print(d["bytes_per_launch"], d["avg_launch_ns"], d["valu_inst_per_64_updates"])
 
 
 if __name__ == "__main__":
