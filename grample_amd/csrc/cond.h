@@ -18,9 +18,12 @@
 //   floor : thr = 1e-6 * total; SEQUENTIALLY for i: if d_i < thr { d_i += thr; thr += 1e-6 * thr }
 //           -- the reference's rule with thr standing for tot * 1e-6 (its delta): same predicate, same
 //           increments, the running total advanced by the same recurrence
-//   draw  : value = #{ i < Card-1 : u >= T_i },  u a 32-bit uniform,
-//           T_i = min(rint(cum_i * 2^32 / total'), 2^32 - 1), total' and cum_i re-summed after the
-//           floor in the block order above (cum inside a block: prefix of the block, then left to right)
+//   draw  : value = #{ i < Card-1 : (double)u * s >= cum_i },  u a 32-bit uniform, s = total' * 2^-32 (exact),
+//           total' and cum_i re-summed after the floor in the block order above (cum inside a block: prefix of the
+//           block, then left to right).  The reference draws r = U * total' and takes the first i with r <= cum_i: the
+//           same law with U quantised to 32 bits.  One multiply per update and one compare per value -- no division, no
+//           per-value scaling.  The memoised tables store the equivalent integer thresholds
+//           T_i = min{ u : (double)u * s >= cum_i } (threshold_u32, exact), so "u >= T_i" there is the same predicate.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,10 +39,10 @@ __device__ __forceinline__ void floor_step(double &d, double &thr, const bool li
     thr = fma(fs * kFloorEps, thr, thr); // the running total grows by its 1e-6 (gibbs-simple.go:255-257)
 }
 
-// Thresholds as f64 integers in [0, 2^32 - 1] (compare with (double)u; store as u32 for the memoised tables).
+// After the floor: the cumulative sums cum[i] (i < Card - 1) and s = total' * 2^-32.
 // FULL = the variable uses all MAXC values: same arithmetic, none of the per-value `i < C` guards.
 template <int MAXC, bool FULL>
-__device__ __forceinline__ void thresholds_impl(const float (&w)[MAXC], const int C, double (&T)[MAXC > 1 ? MAXC - 1 : 1]) {
+__device__ __forceinline__ void cumulative_impl(const float (&w)[MAXC], const int C, double (&cum)[MAXC > 1 ? MAXC - 1 : 1], double &s) {
     constexpr int NB = (MAXC + 3) / 4; // blocks of 4 values
     constexpr int NG = (NB + 3) / 4;   // groups of 4 blocks
     float m = w[0];
@@ -85,40 +88,52 @@ __device__ __forceinline__ void thresholds_impl(const float (&w)[MAXC], const in
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) floor_step(d[i], thr, FULL || i < C); // every value must stay possible (gibbs-simple.go:246-258)
 
-    const double scale = 4294967296.0 / sums(); // WeightedSample re-sums the weights (sampler.go:110-116)
+    s = sums() * 0x1p-32; // WeightedSample re-sums the weights (sampler.go:110-116); r = U * total' becomes (double)u * s
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
-        double cum = 0.0;
+        double c = 0.0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int i = 4 * b + k;
             if (i < MAXC - 1) {
-                cum = (k == 0) ? (b == 0 ? d[i] : P[b] + d[i]) : cum + d[i];
-                if (FULL || i < C - 1) T[i] = fmin(rint(cum * scale), 4294967295.0);
+                c = (k == 0) ? (b == 0 ? d[i] : P[b] + d[i]) : c + d[i];
+                if (FULL || i < C - 1) cum[i] = c;
             }
         }
     }
 }
 
 template <int MAXC>
-__device__ __forceinline__ void thresholds(const float (&w)[MAXC], const int C, double (&T)[MAXC > 1 ? MAXC - 1 : 1]) {
-    if (C == MAXC) thresholds_impl<MAXC, true>(w, C, T);
-    else thresholds_impl<MAXC, false>(w, C, T);
+__device__ __forceinline__ void cumulative(const float (&w)[MAXC], const int C, double (&cum)[MAXC > 1 ? MAXC - 1 : 1], double &s) {
+    if (C == MAXC) cumulative_impl<MAXC, true>(w, C, cum, s);
+    else cumulative_impl<MAXC, false>(w, C, cum, s);
 }
 
+// the categorical draw (sampler.go:117-123): how many cumulative sums the scaled uniform has passed
 template <int MAXC>
-__device__ __forceinline__ uint32_t pick(const double (&T)[MAXC > 1 ? MAXC - 1 : 1], const int C, const uint32_t u) {
-    const double uf = (double)u;
+__device__ __forceinline__ uint32_t pick(const double (&cum)[MAXC > 1 ? MAXC - 1 : 1], const double s, const int C, const uint32_t u) {
+    const double r = (double)u * s;
     uint32_t val = 0;
     if (C == MAXC) {
 #pragma unroll
-        for (int i = 0; i < MAXC - 1; ++i) val += (uf >= T[i]) ? 1u : 0u;
+        for (int i = 0; i < MAXC - 1; ++i) val += (r >= cum[i]) ? 1u : 0u;
     } else {
 #pragma unroll
         for (int i = 0; i < MAXC - 1; ++i)
-            if (i < C - 1) val += (uf >= T[i]) ? 1u : 0u;
+            if (i < C - 1) val += (r >= cum[i]) ? 1u : 0u;
     }
     return val;
+}
+
+// The integer threshold equivalent to one compare of pick(): the smallest u with (double)u * s >= cum, found exactly
+// (u * s is monotone in u; the quotient gives a candidate within one step of it).  Every remaining value keeps a mass
+// of at least 1e-6 of the total after the floor, so such a u always exists below 2^32.  Used by the memoisation kernel
+// and the probe -- "u >= threshold_u32(cum_i, s)" is, for every 32-bit u, the predicate the direct kernels evaluate.
+__device__ __forceinline__ uint32_t threshold_u32(const double cum, const double s) {
+    double t = fmin(ceil(cum / s), 4294967295.0);
+    while (t > 0.0 && (t - 1.0) * s >= cum) t -= 1.0;
+    while (t < 4294967295.0 && t * s < cum) t += 1.0;
+    return (uint32_t)t;
 }
 
 } // namespace gr

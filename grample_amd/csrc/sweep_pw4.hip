@@ -162,16 +162,14 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
                 guess = n;
             }
             const double zq = quad_scan(((e4[0] + e4[1]) + e4[2]) + e4[3], m1, m2);
-            const double scale = 4294967296.0 / qperm_d<kLast>(zq); // WeightedSample re-sums the weights (sampler.go:110-116)
-            const double before = qperm_d<kShr1>(zq);                // sum of the blocks before mine (unused by block 0)
-            const double uf = (double)du;
+            const double r = (double)du * (qperm_d<kLast>(zq) * 0x1p-32); // r = U * total' (sampler.go:110-117), cond.h's pick()
+            const double before = qperm_d<kShr1>(zq);                      // sum of the blocks before mine (unused by block 0)
             double cum = fma(before, m1, e4[0]);
             int cnt = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 if (i > 0) cum += e4[i];
-                const double T = fmin(rint(cum * scale), 4294967295.0);
-                cnt += ((int)(4u * blk) + i < C - 1 && uf >= T) ? 1 : 0;
+                cnt += ((int)(4u * blk) + i < C - 1 && r >= cum) ? 1 : 0;
             }
             cnt += qperm_i<kXor1>(cnt);
             const uint32_t val = (uint32_t)(cnt + qperm_i<kXor2>(cnt));
