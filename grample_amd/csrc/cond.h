@@ -15,9 +15,9 @@
 //               total = (q2 + q3) + (q0 + q1)          (absent blocks count as +0.0, which is exact)
 //           -- a fixed summation order that a lane-per-chain loop and a 4-lanes-per-chain scan both
 //           reproduce exactly (f64; any order is within 1e-16 of the reference's left-to-right sum)
-//   floor : thr = 1e-6 * total; SEQUENTIALLY for i: if d_i < thr { d_i += thr; thr += 1e-6 * thr }
-//           -- the reference's rule with thr standing for tot * 1e-6 (its delta): same predicate, same
-//           increments, the running total advanced by the same recurrence
+//   floor : t0 = 1e-6 * total; SEQUENTIALLY for i, k = floors so far: thr = t0 * (1 + k * 1e-6); if d_i < thr { d_i += thr; k++ }
+//           -- the reference's rule with thr standing for tot * 1e-6 (its delta): same predicate, same increments; the
+//           running total grows linearly in k instead of geometrically (floor_thr: 1.2e-10 relative at Card 16)
 //   draw  : value = #{ i < Card-1 : (double)u * s >= cum_i },  u a 32-bit uniform, s = total' * 2^-32 (exact),
 //           total' and cum_i re-summed after the floor in the block order above (cum inside a block: prefix of the
 //           block, then left to right).  The reference draws r = U * total' and takes the first i with r <= cum_i: the
@@ -32,11 +32,18 @@ namespace gr {
 
 constexpr double kFloorEps = 1e-6; // gibbs-simple.go:248 (probability floor), also the growth of the running total
 
-// one floor step of the sequential rule: value d against the current threshold thr (= 1e-6 x running total)
-__device__ __forceinline__ void floor_step(double &d, double &thr, const bool live) {
+// The floor threshold after k floors: 1e-6 x the running total.  The reference grows the total by its own 1e-6 at every
+// floor, tot_k = tot_0 (1 + 1e-6)^k; here tot_k = tot_0 (1 + k 1e-6) -- the same to within k^2 / 2 * 1e-12 (1.2e-10 relative
+// at Card 16), far inside the f32 exp error -- because this form is a pure function of k: a lane that owns a block of
+// values needs the number of floors before it, not a k-step recurrence.  t0 = 1e-6 * tot_0, te = 1e-6 * t0.
+__device__ __forceinline__ double floor_thr(const double t0, const double te, const double k) { return fma(k, te, t0); }
+
+// one step of the sequential rule (gibbs-simple.go:246-258): value d against the threshold after k floors
+__device__ __forceinline__ void floor_step(double &d, double &k, const double t0, const double te, const bool live) {
+    const double thr = floor_thr(t0, te, k);
     const double fs = (live && d < thr) ? 1.0 : 0.0;
-    d = fma(fs, thr, d);                 // d += thr when floored (fs * thr is exact)
-    thr = fma(fs * kFloorEps, thr, thr); // the running total grows by its 1e-6 (gibbs-simple.go:255-257)
+    d = fma(fs, thr, d); // d += thr when floored (fs * thr is exact)
+    k += fs;
 }
 
 // After the floor: the cumulative sums cum[i] (i < Card - 1) and s = total' * 2^-32.
@@ -84,9 +91,10 @@ __device__ __forceinline__ void cumulative_impl(const float (&w)[MAXC], const in
         return base;
     };
 
-    double thr = kFloorEps * sums();
+    const double t0 = kFloorEps * sums(), te = kFloorEps * t0;
+    double k = 0.0;
 #pragma unroll
-    for (int i = 0; i < MAXC; ++i) floor_step(d[i], thr, FULL || i < C); // every value must stay possible (gibbs-simple.go:246-258)
+    for (int i = 0; i < MAXC; ++i) floor_step(d[i], k, t0, te, FULL || i < C); // every value must stay possible (gibbs-simple.go:246-258)
 
     s = sums() * 0x1p-32; // WeightedSample re-sums the weights (sampler.go:110-116); r = U * total' becomes (double)u * s
 #pragma unroll

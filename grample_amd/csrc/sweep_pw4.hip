@@ -11,10 +11,10 @@
 //   block     256 lanes = 4 wavefronts = the 64 chains of one scan group (same scan stream as every other kernel)
 //   state     lds[var * 64 + chain] (the 4 lanes of a quad read the same byte: broadcast)
 //   tables    view-table rows from global memory (L1/L2): the quad's 4 lanes read the 64 contiguous bytes of one row
-//   floor     the sequential 1e-6 rule (cond.h) couples the blocks through the running total only: each block needs the
-//             number of floors in the blocks before it.  Guess it from the un-grown threshold (a lower bound), advance
-//             the threshold by that many steps, run the block's own 4 values sequentially, and check the guess; a wrong
-//             guess (a value inside the 1e-6-relative window the total moves through) repeats the pass, 4 times at most.
+//   floor     the sequential 1e-6 rule (cond.h) couples the blocks only through the number of floors so far: each block needs
+//             the number of floors in the blocks before it.  Guess it from the un-grown threshold (a lower bound), run the
+//             block's own 4 values sequentially from there, and check the guess; a wrong guess (a value inside the
+//             1e-6-relative window the threshold moves through) repeats the pass, 4 times at most.
 // Same Philox streams, same program order of the f32 log sums, same f64 block sums and floor recurrence as cond.h:
 // results are bit-identical to the chain-per-lane kernel (tests/test_gpu_parity.py::test_value_parallel_form_*).
 #include <hip/hip_runtime.h>
@@ -138,25 +138,22 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) d[i] = (double)__expf(w[i] - m);
             const double tot = qperm_d<kLast>(quad_scan(((d[0] + d[1]) + d[2]) + d[3], m1, m2));
-            const double thr0 = kFloorEps * tot;
+            const double t0 = kFloorEps * tot, te = kFloorEps * t0;
             int guess = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) guess += (live[i] && d[i] < thr0) ? 1 : 0;
+            for (int i = 0; i < 4; ++i) guess += (live[i] && d[i] < t0) ? 1 : 0;
             double e4[4];
             for (;;) {
                 // floors in the blocks before mine = exclusive quad prefix of the guesses
                 int s1 = guess + (k1 & qperm_i<kShr1>(guess));
                 s1 = s1 + (k2 & qperm_i<kShr2>(s1));
-                const int k_in = s1 - guess;
-                double thr = thr0;
-                for (int it = 0; __any(it < k_in); ++it)
-                    if (it < k_in) thr = fma(kFloorEps, thr, thr); // the threshold after k_in floors (floor_step's recurrence)
+                double k = (double)(s1 - guess);
                 int n = 0;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     e4[i] = d[i];
-                    n += (live[i] && e4[i] < thr) ? 1 : 0;
-                    floor_step(e4[i], thr, live[i]);
+                    n += (live[i] && e4[i] < floor_thr(t0, te, k)) ? 1 : 0;
+                    floor_step(e4[i], k, t0, te, live[i]);
                 }
                 if (!__any(n != guess)) break;
                 guess = n;
