@@ -177,13 +177,14 @@ def main():
         per_launch_updates = CHAINS_PER_GPU * upd_per_step * args.steps / max(launches, 1)
         per_launch_s = kernel_ms * 1e-3 / max(launches, 1)
         achieved = ALGO_BYTES_PER_UPDATE * per_launch_updates / per_launch_s / 1e9
-        traffic, valu_per_update = None, None
+        traffic, valu_per_update, sclk = None, None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
             try:
                 prof = json.load(open(tpath))
                 traffic = prof.get("bytes_per_launch")
                 valu_per_update = prof.get("valu_inst_per_64_updates")  # SQ_INSTS_VALU per wave iteration (rocprofv3 --pmc pass)
+                sclk = prof.get("sclk_ghz_measured")
             except Exception:
                 traffic = None
         # what actually bounds the kernel, next to the contract's algorithmic-bytes figure: measured HBM traffic as a
@@ -194,6 +195,8 @@ def main():
         if valu_per_update:
             a = valu_per_update / 64.0 * per_launch_updates / per_launch_s / 1e9
             limiter.update({"achieved": a, "frac": a / VALU_PEAK_GINST, "valu_inst_per_64_updates": valu_per_update})
+            if sclk:  # the same fraction against the clock the chip actually sustained in this kernel (GRBM_GUI_ACTIVE pass)
+                limiter.update({"sclk_ghz_measured": sclk, "frac_at_measured_clock": a / (VALU_PEAK_GINST * sclk / 2.4)})
         hbm_measured = None
         if traffic:
             gbs = traffic / per_launch_s / 1e9

@@ -28,7 +28,7 @@ def main():
                      ("all_models_32768.txt", "all_models_32768.txt")):
         if os.path.exists(os.path.join(G, src)):
             shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{dst}"))
-    for tag in ("fetch", "write", "sqA", "sqB"):
+    for tag in ("fetch", "write", "sqA", "sqB", "gui"):
         src = os.path.join(G, f"pmc_{tag}", "run_counter_collection.csv")
         if os.path.exists(src):
             csv.writer(open(os.path.join(P, f"{TAG}_pmc_{tag}.csv"), "w", newline="")).writerows(kernel_rows(src))
@@ -47,8 +47,16 @@ def main():
     # VALU instructions per 64 updates: one bench step = two sweep launches = 100 000 updates on each of 65 536 chains
     valu = vals("sqA", "SQ_INSTS_VALU", KERN)
     per64 = sum(valu[-2:]) / (100000.0 * 65536.0 / 64.0)
+    # shader clock the chip sustained inside the sweep launches: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / launch duration
+    sclk = None
+    if os.path.exists(os.path.join(P, f"{TAG}_pmc_gui.csv")):
+        gr_ = rows("gui", "GRBM_GUI_ACTIVE", KERN)
+        if gr_:
+            sclk = sum(float(r["Counter_Value"]) / 8.0 / (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in gr_) / len(gr_)
     d = {
         "round": int(TAG[1:]),
+        "sclk_ghz_measured": round(sclk, 3) if sclk else None,
+        "sclk_note": "GRBM_GUI_ACTIVE / 8 XCDs / launch duration of the sweep launches (rocprofv3 --pmc GRBM_GUI_ACTIVE pass)",
         "kernel": f"gr::{KERN} (binary memoised path, 4 lanes per chain, counting) -- the dominant kernel of bench.py",
         "command": "rocprofv3 --pmc FETCH_SIZE (and, separately, WRITE_SIZE; SQ_* in two more passes) --kernel-trace --output-format csv -- python3 bench.py "
                    "--steps 5 --warmup 1 --no-cpu-baseline ; kernel durations from rocprofv3 --kernel-trace --stats of the same command (scripts/collect_profiles.sh)",
