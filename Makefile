@@ -28,9 +28,11 @@ $(OBJDIR)/sweep_bin.o: $(CSRC)/sweep_bin.hip $(CSRC)/kernels.h $(CSRC)/device_la
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
+# max-ilp: the value-parallel kernel runs two independent conditionals per wavefront (pw4_cond<2>); the default scheduler
+# emits them one after the other, this one interleaves their dependent f64 chains
 $(OBJDIR)/sweep_pw4.o: $(CSRC)/sweep_pw4.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/cond.h
 	@mkdir -p $(OBJDIR)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -mllvm -amdgpu-sched-strategy=max-ilp -c $< -o $@
 
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/*.h) $(wildcard $(CSRC)/*.hpp) include/grample_hip.h
 	@mkdir -p $(OBJDIR)

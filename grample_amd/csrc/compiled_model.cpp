@@ -135,8 +135,13 @@ VariantImage CompileVariant(const Model &m, const CompileLimits &lim) {
             const uint32_t nf = pg[0] >> 16, slots = (nf + 7u) & ~7u;
             im.vprog.push_back((pg[0] & 0xffffu) | (slots << 16));
             im.vprog.push_back(pg[1]);
-            im.vprog.push_back(0);
-            im.vprog.push_back(0);
+            // words 2..3: 64-bit filter of the variable's blanket, itself included -- bit (u mod 64) is set for every u whose
+            // update does not commute with this one.  A clear bit proves independence (the kernel then runs two consecutive
+            // steps together); with more than 64 variables a set bit may be a false alarm, which only costs the pairing.
+            uint64_t filt = 1ull << (v & 63);
+            for (uint32_t f = 0; f < nf; ++f) filt |= 1ull << (pg[4 + 4 * f + 1] & 63u);
+            im.vprog.push_back((uint32_t)filt);
+            im.vprog.push_back((uint32_t)(filt >> 32));
             for (uint32_t f = 0; f < slots; ++f) {
                 const uint32_t *e = pg + 4 + 4 * f;
                 const bool real = f < nf;

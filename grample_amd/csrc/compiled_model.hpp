@@ -41,7 +41,8 @@ struct VariantImage {
     bool pairwise = false;
     std::vector<uint32_t> pprog, pprog_off;
     // value-parallel form of the pairwise program (k_sweep_pw4), per variable:
-    //   [0] Card | rowlen << 8 | n_slots << 16 (n_slots = factors rounded up to 8), [1] histogram offset, [2..3] pad, then per
+    //   [0] Card | rowlen << 8 | n_slots << 16 (n_slots = factors rounded up to 8), [1] histogram offset, [2..3] 64-bit filter
+    //   of the variable's blanket (bit u mod 64; itself included), then per
     //   slot one 16-byte entry {view BYTE offset, other var * 64 (its LDS state row), BYTE stride, 0}; the slots past the
     //   last factor point at the all-zero row `zero_row` with stride 0, so the kernel needs no guards.
     std::vector<uint32_t> vprog, vprog_off;

@@ -59,7 +59,83 @@ __device__ __forceinline__ double quad_scan(const double q, const double m1, con
 
 } // namespace
 
-template <int GF>
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+
+// One step's wave-uniform inputs (scalar registers)
+struct StepHdr {
+    uint32_t v;          // the variable updated
+    const uint32_t *pg;  // its value-parallel program
+    uint32_t h, ho;      // Card | rowlen << 8 | n_slots << 16, histogram offset
+    uint32_t f_lo, f_hi; // filter of its blanket (compiled_model.hpp)
+};
+
+// cond.h across a DPP quad for NP independent steps at once (NP = 2: two consecutive steps of a chain whose variables are
+// not adjacent -- both conditionals depend on the state before either commit, so their long dependent f64 chains can be
+// interleaved instruction by instruction; with only two wavefronts per SIMD that interleaving is what fills the VALU).
+// w[p][i]: f32 log sums of my 4 values of step p; returns the drawn values.
+template <int NP>
+__device__ __forceinline__ void pw4_cond(float (&w)[NP][4], const int (&C)[NP], const uint32_t (&du)[NP], const uint32_t blk, const double m1,
+                                         const double m2, const int k1, const int k2, uint32_t (&val)[NP]) {
+    bool live[NP][4];
+    double d[NP][4], t0[NP], te[NP], e4[NP][4];
+    int guess[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            live[p][i] = (int)(4u * blk) + i < C[p];
+            w[p][i] = live[p][i] ? w[p][i] : -INFINITY; // absent values: exp -> +0.0, never floored, never drawn
+        }
+        float m = fmaxf(fmaxf(w[p][0], w[p][1]), fmaxf(w[p][2], w[p][3]));
+        m = fmaxf(m, qperm_f<kXor1>(m));
+        m = fmaxf(m, qperm_f<kXor2>(m));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d[p][i] = (double)__expf(w[p][i] - m);
+        const double tot = qperm_d<kLast>(quad_scan(((d[p][0] + d[p][1]) + d[p][2]) + d[p][3], m1, m2));
+        t0[p] = kFloorEps * tot;
+        te[p] = kFloorEps * t0[p];
+        guess[p] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) guess[p] += (live[p][i] && d[p][i] < t0[p]) ? 1 : 0;
+    }
+    for (;;) {
+        bool again = false;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            // floors in the blocks before mine = exclusive quad prefix of the guesses
+            int s1 = guess[p] + (k1 & qperm_i<kShr1>(guess[p]));
+            s1 = s1 + (k2 & qperm_i<kShr2>(s1));
+            double k = (double)(s1 - guess[p]);
+            int n = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                e4[p][i] = d[p][i];
+                n += (live[p][i] && e4[p][i] < floor_thr(t0[p], te[p], k)) ? 1 : 0;
+                floor_step(e4[p][i], k, t0[p], te[p], live[p][i]);
+            }
+            again = again || n != guess[p];
+            guess[p] = n;
+        }
+        if (!__any(again)) break;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const double zq = quad_scan(((e4[p][0] + e4[p][1]) + e4[p][2]) + e4[p][3], m1, m2);
+        const double r = (double)du[p] * (qperm_d<kLast>(zq) * 0x1p-32); // r = U * total' (sampler.go:110-117), cond.h's pick()
+        const double before = qperm_d<kShr1>(zq);                         // sum of the blocks before mine (unused by block 0)
+        double cum = fma(before, m1, e4[p][0]);
+        int cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i > 0) cum += e4[p][i];
+            cnt += ((int)(4u * blk) + i < C[p] - 1 && r >= cum) ? 1 : 0;
+        }
+        cnt += qperm_i<kXor1>(cnt);
+        val[p] = (uint32_t)(cnt + qperm_i<kXor2>(cnt));
+    }
+}
+
 __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -86,94 +162,99 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
     const double m1 = blk >= 1u ? 1.0 : 0.0, m2 = blk >= 2u ? 1.0 : 0.0;
     const int k1 = blk >= 1u ? -1 : 0, k2 = blk >= 2u ? -1 : 0; // the same as integer masks
 
+    // VarSample (sampler.go:135-174) + the selected variable's program header
+    auto header = [&](const uint32_t su) -> StepHdr {
+        StepHdr h;
+        h.v = freev[uni_p(mul_hi_u32(uni_p(su), vd.n_free))];
+        h.pg = progs + poff[h.v];
+        const uint4 w = *reinterpret_cast<const uint4 *>(h.pg);
+        h.h = w.x; h.ho = w.y; h.f_lo = w.z; h.f_hi = w.w;
+        return h;
+    };
+    // f32 log sums of my 4 values, factors in Model.Funcs order (gibbs-simple.go:186).  The padding slots of the program read
+    // an all-zero row (w + 0.0f is w), so nothing here is guarded: per slot one state byte, one multiply-add for the row
+    // offset, one 16-byte load, two packed adds.
+    // With two wavefronts per SIMD every instruction of a wavefront costs issue time, scalar ones included (measured: ~1
+    // instruction per 4 cycles and SIMD whatever the mix), so the loop is built to need few of them: the 8 entries of a slot
+    // group arrive as two s_load_dwordx16, and the row loads are buffer loads -- the entry's table offset goes into the
+    // instruction's scalar-offset operand instead of a 64-bit scalar add per slot.
+    const __amdgpu_buffer_rsrc_t views_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char *>(tab), 0, 0x7fffffff, 0x00020000);
+    auto gather = [&](const StepHdr &h, float (&w)[4]) {
+        const uint32_t rowlen = (h.h >> 8) & 0xffu, n_slots = h.h >> 16; // slots = factors padded to a multiple of 8
+        // byte offset of my block inside a row; a lane whose block lies past the variable's rows reads block 0 instead
+        // (valid memory; its values are marked absent in pw4_cond)
+        const uint32_t col = 4u * blk < rowlen ? 16u * blk : 0u;
+        w[0] = w[1] = w[2] = w[3] = 0.f;
+        const u32x16 *ent = reinterpret_cast<const u32x16 *>(h.pg + 4); // 4 entries of {table offset, state row, stride, 0} each
+        for (uint32_t f0 = 0; f0 < n_slots; f0 += 8) {
+            const u32x16 ea = ent[f0 >> 2], eb = ent[(f0 >> 2) + 1u];
+            uint32_t ex[8], ey[8], ez[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ex[i] = ea[4 * i]; ey[i] = ea[4 * i + 1]; ez[i] = ea[4 * i + 2];
+                ex[4 + i] = eb[4 * i]; ey[4 + i] = eb[4 * i + 1]; ez[4 + i] = eb[4 * i + 2];
+            }
+            uint32_t x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = (uint32_t)st[ey[i]];
+            u32x4v r[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(views_rsrc, __umul24(x[i], ez[i]) + col, ex[i], 0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                w[0] += __uint_as_float(r[i][0]); w[1] += __uint_as_float(r[i][1]);
+                w[2] += __uint_as_float(r[i][2]); w[3] += __uint_as_float(r[i][3]);
+            }
+        }
+    };
+    // g.last[v] = val (gibbs-simple.go:267) and Marginal[val] += 1 (chain.go:230-236)
+    auto commit = [&](const StepHdr &h, const uint32_t val) {
+        if (blk == 0u) {
+            st[h.v * 64u] = (unsigned char)val;
+            if (counting) atomicAdd(&hist[h.ho + val], 1u);
+        }
+    };
+
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
         const u32x4 sc = philox4x32_10<true>(q_lo, q_hi, group_gid, DOM_SCAN, p.seed_lo, p.seed_hi);                       // scalar unit
         const u32x4 dr = philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
+        int j = 0;
 #pragma unroll 1
-        for (int j = 0; j < 4; ++j) {
+        while (j < 4) {
             const uint64_t s = (q << 2) + j;
-            if (s < step0 || s >= step1) continue;
-            const uint32_t su = j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w; // (no register arrays indexed by j)
-            const uint32_t du = j == 0 ? dr.x : j == 1 ? dr.y : j == 2 ? dr.z : dr.w;
-            const uint32_t v = freev[uni_p(mul_hi_u32(uni_p(su), vd.n_free))]; // VarSample (sampler.go:135-174)
-            const uint32_t *pg = progs + poff[v];
-            const uint32_t h = pg[0];
-            const int C = (int)(h & 0xffu);
-            const uint32_t rowlen = (h >> 8) & 0xffu, n_slots = h >> 16; // slots = factors padded to a multiple of GF
-            const uint32_t ho = pg[1];
-            // byte offset of my block inside a row; a lane whose block lies past the variable's rows reads block 0 instead
-            // (valid memory; its values are marked absent below)
-            const uint32_t col = 4u * blk < rowlen ? 16u * blk : 0u;
-
-            // ---- f32 log sums of my 4 values, factors in Model.Funcs order (gibbs-simple.go:186).  The padding slots of
-            // the program read an all-zero row (w + 0.0f is w), so nothing here is guarded: per slot one state byte, one
-            // multiply-add for the row offset, one 16-byte load, two packed adds.
-            float w[4] = {0.f, 0.f, 0.f, 0.f};
-            const uint4 *ent = reinterpret_cast<const uint4 *>(pg + 4);
-            for (uint32_t f0 = 0; f0 < n_slots; f0 += GF) {
-                uint4 e[GF];
-#pragma unroll
-                for (int i = 0; i < GF; ++i) e[i] = ent[f0 + (uint32_t)i];
-                uint32_t x[GF];
-#pragma unroll
-                for (int i = 0; i < GF; ++i) x[i] = (uint32_t)st[e[i].y];
-                float4 r[GF];
-#pragma unroll
-                for (int i = 0; i < GF; ++i) r[i] = *reinterpret_cast<const float4 *>(tab + e[i].x + (__umul24(x[i], e[i].z) + col));
-#pragma unroll
-                for (int i = 0; i < GF; ++i) { w[0] += r[i].x; w[1] += r[i].y; w[2] += r[i].z; w[3] += r[i].w; }
+            if (s < step0 || s >= step1) { ++j; continue; }
+            const StepHdr ha = header(j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w); // (no register arrays indexed by j)
+            const uint32_t dua = j == 0 ? dr.x : j == 1 ? dr.y : j == 2 ? dr.z : dr.w;
+            // the next step runs together with this one when it exists and its variable is neither this one nor a neighbour
+            bool pair = j < 3 && s + 1 < step1;
+            StepHdr hb = ha;
+            if (pair) {
+                hb = header(j == 0 ? sc.y : j == 1 ? sc.z : sc.w);
+                const uint32_t bit = hb.v & 63u;
+                pair = (((bit < 32u ? ha.f_lo >> bit : ha.f_hi >> (bit - 32u)) & 1u) == 0u);
             }
-            bool live[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                live[i] = (int)(4u * blk) + i < C;
-                w[i] = live[i] ? w[i] : -INFINITY; // absent values: exp -> +0.0, never floored, never drawn
-            }
-            // ---- cond.h, value-parallel
-            float m = fmaxf(fmaxf(w[0], w[1]), fmaxf(w[2], w[3]));
-            m = fmaxf(m, qperm_f<kXor1>(m));
-            m = fmaxf(m, qperm_f<kXor2>(m));
-            double d[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d[i] = (double)__expf(w[i] - m);
-            const double tot = qperm_d<kLast>(quad_scan(((d[0] + d[1]) + d[2]) + d[3], m1, m2));
-            const double t0 = kFloorEps * tot, te = kFloorEps * t0;
-            int guess = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) guess += (live[i] && d[i] < t0) ? 1 : 0;
-            double e4[4];
-            for (;;) {
-                // floors in the blocks before mine = exclusive quad prefix of the guesses
-                int s1 = guess + (k1 & qperm_i<kShr1>(guess));
-                s1 = s1 + (k2 & qperm_i<kShr2>(s1));
-                double k = (double)(s1 - guess);
-                int n = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    e4[i] = d[i];
-                    n += (live[i] && e4[i] < floor_thr(t0, te, k)) ? 1 : 0;
-                    floor_step(e4[i], k, t0, te, live[i]);
-                }
-                if (!__any(n != guess)) break;
-                guess = n;
-            }
-            const double zq = quad_scan(((e4[0] + e4[1]) + e4[2]) + e4[3], m1, m2);
-            const double r = (double)du * (qperm_d<kLast>(zq) * 0x1p-32); // r = U * total' (sampler.go:110-117), cond.h's pick()
-            const double before = qperm_d<kShr1>(zq);                      // sum of the blocks before mine (unused by block 0)
-            double cum = fma(before, m1, e4[0]);
-            int cnt = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (i > 0) cum += e4[i];
-                cnt += ((int)(4u * blk) + i < C - 1 && r >= cum) ? 1 : 0;
-            }
-            cnt += qperm_i<kXor1>(cnt);
-            const uint32_t val = (uint32_t)(cnt + qperm_i<kXor2>(cnt));
-            // ---- g.last[v] = val (gibbs-simple.go:267) and Marginal[val] += 1 (chain.go:230-236)
-            if (blk == 0u) {
-                st[v * 64u] = (unsigned char)val;
-                if (counting) atomicAdd(&hist[ho + val], 1u);
+            if (pair) {
+                const uint32_t dub = j == 0 ? dr.y : j == 1 ? dr.z : dr.w;
+                float w[2][4];
+                gather(ha, w[0]);
+                gather(hb, w[1]);
+                const int C[2] = {(int)(ha.h & 0xffu), (int)(hb.h & 0xffu)};
+                const uint32_t du[2] = {dua, dub};
+                uint32_t val[2];
+                pw4_cond<2>(w, C, du, blk, m1, m2, k1, k2, val);
+                commit(ha, val[0]);
+                commit(hb, val[1]);
+                j += 2;
+            } else {
+                float w[1][4];
+                gather(ha, w[0]);
+                const int C[1] = {(int)(ha.h & 0xffu)};
+                const uint32_t du[1] = {dua};
+                uint32_t val[1];
+                pw4_cond<1>(w, C, du, blk, m1, m2, k1, k2, val);
+                commit(ha, val[0]);
+                j += 1;
             }
         }
     }
@@ -190,9 +271,9 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
 }
 
 hipError_t launch_sweep_pw4(const SweepParams &p, uint32_t blocks, uint32_t lds_bytes, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_pw4<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_pw4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_sweep_pw4<8>), dim3(blocks), dim3(256), lds_bytes, s, p);
+    hipLaunchKernelGGL(k_sweep_pw4, dim3(blocks), dim3(256), lds_bytes, s, p);
     return hipGetLastError();
 }
 
