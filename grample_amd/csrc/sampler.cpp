@@ -264,6 +264,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
         const bool use_cpt = (pass == 0) && all_cpt;
         if (pass == 0 && !use_cpt) continue;
         for (bool tl : {true, false}) { // tables (thresholds or views) staged in LDS, else read from global memory / L2
+            bool prefer_global_tables = false;
             for (uint32_t t : cands) {
                 if (o.n_variants > 1 && cpv % t) continue;
                 uint32_t ho, to;
@@ -309,11 +310,28 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                     // the plan ring: the "lean" layout ends after the tables.  (Without it such models ran the chain-per-lane
                     // form with one 64-lane block per CU: 125 KB of LDS behind a single wavefront.)
                     par_lean = (!tl || b2 > kLdsBudget) && par_rec_off <= kLdsBudget && !try_strict_fast && (o.fast_form < 4 || o.fast_form == 6);
+                    // ... and whenever dropping the LDS records lets a CU hold more of the blocks it is going to get (collapsed
+                    // Segmentation_11, 128 groups: 100 KB -> 62 KB per block = 2 resident blocks per CU instead of 1)
+                    if (!par_lean && b2 <= kLdsBudget && !try_strict_fast && o.fast_form == 0) {
+                        const uint32_t need = (o.n_chains / 64u + 255u) / 256u; // blocks per CU if all were resident
+                        if (std::min(kLdsBudget / par_rec_off, need) > std::min(kLdsBudget / b2, need)) par_lean = true;
+                    }
                     if (par_lean) par_lds = par_rec_off;
                     par_tabg = !tl;
                     par = par_lds <= kLdsBudget && (slots <= 6 || fits16) && (o.n_variants == 1 || cpv % 64u == 0) && (o.n_chains % 64u) == 0;
                     if (par) fast = true;
                     else par_tabg = false;
+                    // Thresholds in LDS are faster than thresholds from L2 at equal occupancy (Segmentation_11: 3.6e11 vs 2.9e11),
+                    // but not when they keep a CU at ONE block while it has two or more to run (the same model collapsed in
+                    // 128 groups: 17 K words per group, 88 KB per block even without records -- 2.0e11 vs 2.2e11): then leave
+                    // them in global memory.
+                    if (par && tl && !try_strict_fast && o.fast_form == 0) {
+                        const uint32_t need = (o.n_chains / 64u + 255u) / 256u;
+                        if (std::min(kLdsBudget / par_lds, need) < 2u && std::min(kLdsBudget / std::max(par_tab_off, 1u), need) >= 2u) {
+                            prefer_global_tables = true;
+                            break;
+                        }
+                    }
                 }
                 // direct path, LDS-resident state, but the footprint keeps most wavefronts waiting for a CU (Alchemy_11 at
                 // 131 072 chains: 108 KB per 128-lane block = 512 resident wavefronts for 2 048): leave the state in global
@@ -323,6 +341,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                     state_global();
                 return;
             }
+            if (prefer_global_tables) continue; // -> the tl = false candidate
         }
     }
     state_global(); // no LDS layout holds the chain state (n_vars * 64 bytes > 160 KiB): leave it in global memory
@@ -1502,7 +1521,9 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
     return guarded([&] {
         if (!s || !out || out->struct_size != sizeof(gr_sampler_info)) throw Error(GR_E_INVALID, "bad gr_sampler_info");
         if (s->dirty) { s->use(); s->configure(); }
-        out->block_threads = s->T; out->n_blocks = s->blocks; out->lds_bytes = s->lds;
+        out->block_threads = s->T; out->n_blocks = s->blocks;
+        out->lds_bytes = s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->lds; // of the kernel that actually runs
+        if (s->fast && s->par) { out->block_threads = s->strict_fast ? s->T : 256u; out->n_blocks = s->active_chains() / 64u; }
         out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
