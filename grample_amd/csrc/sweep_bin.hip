@@ -328,8 +328,7 @@ __device__ __forceinline__ uint32_t comp4(const uint4 &v, int i) { return i == 0
 template <int SLOTS, bool PACKED, bool TABG = false>
 __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const unsigned char *lds_c, const unsigned char *tabg, const uint32_t u) {
     uint32_t cfg4 = 0;
-#pragma unroll
-    for (int i = 0; i < SLOTS; ++i) {
+    auto slot = [&](const int i) {
         uint32_t off, m4;
         if constexpr (PACKED) {
             const uint32_t w = comp4<SLOTS, PACKED>(r.s[i / 4], i % 4);
@@ -340,7 +339,17 @@ __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const
             m4 = comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2) + 1);
         }
         cfg4 += __umul24(m4, (uint32_t)lds_c[off]);
-    }
+    };
+    // 128-byte records (13..16 slots: a collapsed group, where only the few neighbours of the collapsed variable have more
+    // than 8 neighbours): slots 9.. are walked only when one of the wavefront's four steps needs them
+    constexpr int HEAD = SLOTS > 12 ? 8 : SLOTS;
+#pragma unroll
+    for (int i = 0; i < HEAD; ++i) slot(i);
+    if constexpr (SLOTS > HEAD)
+        if (__any(r.h.w > (uint32_t)HEAD)) {
+#pragma unroll
+            for (int i = HEAD; i < SLOTS; ++i) slot(i);
+        }
     const uint32_t T = TABG ? *reinterpret_cast<const uint32_t *>(tabg + (r.h.z + cfg4))
                             : *lds_at(r.h.z + cfg4); // r.h.z: absolute LDS address (staged records)
     return (u >= T) ? 1u : 0u;
