@@ -34,6 +34,8 @@ struct SweepParams {
     const uint32_t *pprog_off;
     const uint32_t *vprogs;     // value-parallel pairwise programs (k_sweep_pw4), same condition
     const uint32_t *vprog_off;
+    const unsigned short *scan_vars; // k_sweep_pw4: the launch's variables, 4 per quad and 64-chain group (k_scan_vars)
+    uint32_t scan_pitch;             // quads per group row of scan_vars
     unsigned char *state;       // [n_vars][pitch] chain-minor: one coalesced 64-B line per wave per variable
     unsigned long long *counts; // [n_variants][H]
     uint32_t n_vars;

@@ -36,6 +36,7 @@ hipError_t launch_build_cpt(const VariantDesc &vd, const uint32_t *progs, const 
 hipError_t launch_conditional(const VariantDesc &vd, const uint32_t *progs, const uint32_t *prog_off, const float *views,
                               uint32_t v, const int32_t *state, double *probs, int max_card, hipStream_t s);
 hipError_t launch_collapse(const CollapseArgs &a, uint32_t blocks, hipStream_t s);
+hipError_t launch_scan_vars(const ScanArgs &a, uint32_t n_quads, uint32_t pitch_quads, unsigned short *out, hipStream_t s);
 hipError_t launch_stop_time(const ScanArgs &a, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *out, hipStream_t s);
 hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
                               uint32_t log_vals, const uint32_t *limit, uint32_t *hist, uint32_t *status, hipStream_t s);

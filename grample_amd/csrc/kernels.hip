@@ -478,6 +478,19 @@ struct ScanReplay {
     }
 };
 
+// The variables a launch of the value-parallel kernel (k_sweep_pw4) will update, evaluated once at full occupancy instead of
+// by every one of its wavefronts on the scalar unit (~100 scalar instructions per quad and wavefront, and the Philox key
+// schedule's registers): out[(group * pitch_quads + quad) * 4 + j] = variable of step 4 * (q0 + quad) + j.
+__global__ void __launch_bounds__(256) k_scan_vars(const ScanArgs a, uint32_t n_quads, uint32_t pitch_quads, unsigned short *out) {
+    const uint32_t qi = blockIdx.x * 256u + threadIdx.x, g = blockIdx.y;
+    if (qi >= n_quads) return;
+    const ScanReplay sr(a, g);
+    const uint64_t q = ((((uint64_t)a.step0_hi << 32) | a.step0_lo) >> 2) + qi;
+    uint32_t v[4];
+    sr.quad(q, v);
+    reinterpret_cast<uint2 *>(out)[(size_t)g * pitch_quads + qi] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+}
+
 // AdvanceChain's stopping rule (chain.go:184-215): batches of `batch` (= 2 N) updates until every selectable
 // variable of the group has been selected cw + 1 more times.  out[group] = number of batches.
 // One wavefront per group; selection counters in LDS (n_vars words).
@@ -661,6 +674,12 @@ hipError_t launch_conditional(const VariantDesc &vd, const uint32_t *progs, cons
     GR_DISPATCH_MAXC(max_card, {
         hipLaunchKernelGGL((k_conditional<MC>), dim3(1), dim3(1), 0, s, vd, progs, prog_off, views, v, state, probs);
     });
+    return hipGetLastError();
+}
+
+hipError_t launch_scan_vars(const ScanArgs &a, uint32_t n_quads, uint32_t pitch_quads, unsigned short *out, hipStream_t s) {
+    if (n_quads == 0 || a.n_groups == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_scan_vars, dim3((n_quads + 255u) / 256u, a.n_groups), dim3(256), 0, s, a, n_quads, pitch_quads, out);
     return hipGetLastError();
 }
 

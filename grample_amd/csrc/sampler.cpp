@@ -112,6 +112,8 @@ struct gr_sampler {
     bool stg = false;                 // chain state stays in global memory (k_sweep<.., STG>): models whose state does not fit LDS
     bool pw4 = false;                 // value-parallel form of the direct path (k_sweep_pw4): pairwise, 8 < Card <= 16
     uint32_t pw4_hist_off = 0, pw4_lds = 0;
+    DevBuf<unsigned short> d_scan_vars; // k_sweep_pw4: the variables of one launch (k_scan_vars), 8 bytes per quad and 64-chain group
+    uint32_t pw4_plan_steps = 0;        // steps per k_sweep_pw4 launch (row length of d_scan_vars, multiple of 4)
     bool strict_fast = false;         // GR_FLAG_SCAN_PER_CHAIN on memoised tables (k_sweep_strict, the 4-lane form's LDS layout)
     uint32_t par_hist_off = 0, par_tab_off = 0, par_rec_off = 0, par_plan_off = 0, par_scr_off = 0, par_lds = 0;
     // device pools
@@ -499,8 +501,15 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     hip_check(hipEventRecord(ev0, stream), "hipEventRecord");
     auto generic = [&](uint64_t n_total) {
         uint64_t left = n_total;
+        const bool use_pw4 = pw4 && !cur_log; // (a logged window runs the chain-per-lane kernel, the only one built with the log code)
+        if (use_pw4 && !d_scan_vars.p) {
+            // <= 256 MiB of scan variables per launch (2 bytes per step and 64-chain group), + 2 quads of slack for unaligned ends
+            const uint64_t groups = o.n_chains / 64u;
+            pw4_plan_steps = (uint32_t)std::max<uint64_t>(std::min<uint64_t>((256ull << 20) / (groups * 2ull), kMaxStepsPerLaunch) & ~3ull, 64);
+            d_scan_vars.alloc((size_t)groups * (pw4_plan_steps + 8u));
+        }
         while (left) {
-            const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
+            const uint32_t n = (uint32_t)std::min<uint64_t>(left, use_pw4 ? pw4_plan_steps : kMaxStepsPerLaunch);
             p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
             p.n_steps = n;
             p.log = cur_log; p.log_pitch = cur_log_pitch; p.log_rows = cur_log_rows; p.log_vals = cur_log_vals;
@@ -510,7 +519,15 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             // area holds thresholds, so the views are read from global memory
             // ... and a logged window (gr_advance_chain) always runs the direct back-end, the only one built with the log code
             const bool plain = strict_fast || cur_log != nullptr;
-            if (pw4 && !cur_log) { // (a logged window runs the chain-per-lane kernel, the only one built with the log code)
+            if (use_pw4) {
+                ScanArgs a{};
+                a.variants = d_variants.p; a.free_vars = d_free.p; a.n_groups = act / 64u; a.chains_per_variant = cpv;
+                a.chain_offset_lo = p.chain_offset_lo; a.chain_offset_hi = p.chain_offset_hi;
+                a.seed_lo = p.seed_lo; a.seed_hi = p.seed_hi; a.n_vars = (uint32_t)n_vars;
+                a.step0_lo = p.step0_lo; a.step0_hi = p.step0_hi;
+                const uint32_t n_quads = (uint32_t)(((step + n - 1) >> 2) - (step >> 2) + 1);
+                p.scan_vars = d_scan_vars.p; p.scan_pitch = pw4_plan_steps / 4u + 2u;
+                hip_check(launch_scan_vars(a, n_quads, p.scan_pitch, d_scan_vars.p, stream), "k_scan_vars launch");
                 p.lds_hist_off = pw4_hist_off;
                 hip_check(launch_sweep_pw4(p, act / 64u, pw4_lds, stream), "k_sweep_pw4 launch");
                 p.lds_hist_off = lds_hist_off;

@@ -29,8 +29,6 @@ namespace gr {
 
 namespace {
 
-__device__ __forceinline__ uint32_t uni_p(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
-
 // quad_perm:[a,b,c,d]: lane i of every quad reads lane {a,b,c,d}[i] of the same quad
 constexpr int QP(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
 constexpr int kShr1 = QP(0, 0, 1, 2); // lane c <- lane c-1 (lane 0 keeps its own)
@@ -151,21 +149,20 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
     __syncthreads();
 
     const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
-    const uint32_t group_gid = uni_p((uint32_t)(gchain >> 6)); // the block's scan stream
+    const uint2 *plan = reinterpret_cast<const uint2 *>(p.scan_vars) + (size_t)blockIdx.x * p.scan_pitch; // the block's scan stream
     const uint64_t step0 = ((uint64_t)p.step0_hi << 32) | p.step0_lo;
     const uint64_t step1 = step0 + p.n_steps;
     const uint32_t *progs = p.vprogs + vd.vprog_base;
     const uint32_t *poff = p.vprog_off + vd.progoff_base;
-    const uint32_t *freev = p.free_vars + vd.free_base;
     const unsigned char *tab = reinterpret_cast<const unsigned char *>(p.views + vd.views_base);
     const bool counting = p.counting != 0;
     const double m1 = blk >= 1u ? 1.0 : 0.0, m2 = blk >= 2u ? 1.0 : 0.0;
     const int k1 = blk >= 1u ? -1 : 0, k2 = blk >= 2u ? -1 : 0; // the same as integer masks
 
-    // VarSample (sampler.go:135-174) + the selected variable's program header
-    auto header = [&](const uint32_t su) -> StepHdr {
+    // the selected variable's (VarSample, sampler.go:135-174: evaluated by k_scan_vars for the whole launch) program header
+    auto header = [&](const uint32_t v) -> StepHdr {
         StepHdr h;
-        h.v = freev[uni_p(mul_hi_u32(uni_p(su), vd.n_free))];
+        h.v = v;
         h.pg = progs + poff[h.v];
         const uint4 w = *reinterpret_cast<const uint4 *>(h.pg);
         h.h = w.x; h.ho = w.y; h.f_lo = w.z; h.f_hi = w.w;
@@ -217,20 +214,21 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
 
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
-        const u32x4 sc = philox4x32_10<true>(q_lo, q_hi, group_gid, DOM_SCAN, p.seed_lo, p.seed_hi);                       // scalar unit
+        const uint2 sv = plan[q - (step0 >> 2)]; // the quad's four variables, 16 bits each
+        const uint32_t sc[4] = {sv.x & 0xffffu, sv.x >> 16, sv.y & 0xffffu, sv.y >> 16};
         const u32x4 dr = philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
         int j = 0;
 #pragma unroll 1
         while (j < 4) {
             const uint64_t s = (q << 2) + j;
             if (s < step0 || s >= step1) { ++j; continue; }
-            const StepHdr ha = header(j == 0 ? sc.x : j == 1 ? sc.y : j == 2 ? sc.z : sc.w); // (no register arrays indexed by j)
+            const StepHdr ha = header(j == 0 ? sc[0] : j == 1 ? sc[1] : j == 2 ? sc[2] : sc[3]); // (no register arrays indexed by j)
             const uint32_t dua = j == 0 ? dr.x : j == 1 ? dr.y : j == 2 ? dr.z : dr.w;
             // the next step runs together with this one when it exists and its variable is neither this one nor a neighbour
             bool pair = j < 3 && s + 1 < step1;
             StepHdr hb = ha;
             if (pair) {
-                hb = header(j == 0 ? sc.y : j == 1 ? sc.z : sc.w);
+                hb = header(j == 0 ? sc[1] : j == 1 ? sc[2] : sc[3]);
                 const uint32_t bit = hb.v & 63u;
                 pair = (((bit < 32u ? ha.f_lo >> bit : ha.f_hi >> (bit - 32u)) & 1u) == 0u);
             }
