@@ -72,9 +72,10 @@ struct StepHdr {
 // not adjacent -- both conditionals depend on the state before either commit, so their long dependent f64 chains can be
 // interleaved instruction by instruction; with only two wavefronts per SIMD that interleaving is what fills the VALU).
 // w[p][i]: f32 log sums of my 4 values of step p; returns the drawn values.
-template <int NP>
-__device__ __forceinline__ void pw4_cond(float (&w)[NP][4], const int (&C)[NP], const uint32_t (&du)[NP], const uint32_t blk, const double m1,
-                                         const double m2, const int k1, const int k2, uint32_t (&val)[NP]) {
+// FULL = every step has Card 16 (all 16 values of the quad live): none of the per-value guards.
+template <int NP, bool FULL>
+__device__ __forceinline__ void pw4_cond_impl(float (&w)[NP][4], const int (&C)[NP], const uint32_t (&du)[NP], const uint32_t blk, const double m1,
+                                              const double m2, const int k1, const int k2, uint32_t (&val)[NP]) {
     bool live[NP][4];
     double d[NP][4], t0[NP], te[NP], e4[NP][4];
     int guess[NP];
@@ -82,7 +83,7 @@ __device__ __forceinline__ void pw4_cond(float (&w)[NP][4], const int (&C)[NP], 
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            live[p][i] = (int)(4u * blk) + i < C[p];
+            live[p][i] = FULL || (int)(4u * blk) + i < C[p];
             w[p][i] = live[p][i] ? w[p][i] : -INFINITY; // absent values: exp -> +0.0, never floored, never drawn
         }
         float m = fmaxf(fmaxf(w[p][0], w[p][1]), fmaxf(w[p][2], w[p][3]));
@@ -127,11 +128,21 @@ __device__ __forceinline__ void pw4_cond(float (&w)[NP][4], const int (&C)[NP], 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i > 0) cum += e4[p][i];
-            cnt += ((int)(4u * blk) + i < C[p] - 1 && r >= cum) ? 1 : 0;
+            cnt += ((FULL ? (blk != 3u || i != 3) : (int)(4u * blk) + i < C[p] - 1) && r >= cum) ? 1 : 0;
         }
         cnt += qperm_i<kXor1>(cnt);
         val[p] = (uint32_t)(cnt + qperm_i<kXor2>(cnt));
     }
+}
+
+template <int NP>
+__device__ __forceinline__ void pw4_cond(float (&w)[NP][4], const int (&C)[NP], const uint32_t (&du)[NP], const uint32_t blk, const double m1,
+                                         const double m2, const int k1, const int k2, uint32_t (&val)[NP]) {
+    bool full = true;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) full = full && C[p] == 16;
+    if (full) pw4_cond_impl<NP, true>(w, C, du, blk, m1, m2, k1, k2, val); // (uniform: Card is a property of the step's variable)
+    else pw4_cond_impl<NP, false>(w, C, du, blk, m1, m2, k1, k2, val);
 }
 
 __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
