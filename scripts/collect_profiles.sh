@@ -6,6 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02
 mkdir -p $O
+rm -f $O/seed_noise.txt
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || exit 1
 echo "bench done"; tail -c 600 $O/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
@@ -22,4 +23,9 @@ echo "configs done"
 python3 $R/scripts/dev_time.py > $O/dev_time.txt 2>&1
 python3 $R/scripts/dev_od.py > $O/dev_od.txt 2>&1
 python3 $R/scripts/dev_all_models.py 32768 > $O/all_models_32768.txt 2>&1
+python3 $R/scripts/parity_configs.py > $O/parity_configs.jsonl 2> $O/parity_configs.err
+for spec in "ObjectDetection_13.uai 256 50 400" "Segmentation_11.uai 256 20 100" "Grids_13.uai 256 20 200"; do
+  echo "== $spec (model chains burn-in-sweeps counted-sweeps; 6 seeds each)" >> $O/seed_noise.txt
+  python3 $R/scripts/dev_noise.py $spec 2>&1 | tail -8 >> $O/seed_noise.txt
+done
 echo "all done"
