@@ -337,6 +337,21 @@ def _pairwise_big_card_model(rng, n=24):
     return SimpleNamespace(card=card, scopes=scopes, tables=tables, fixed=fixed)
 
 
+def test_cross_form_fuzz():
+    """scripts/fuzz_forms.py: 32 random models of four shapes (large-Card pairwise, sparse binary, medium-blanket binary, small
+    mixed cards with arity up to 4, evidence, near-zero entries) through every kernel form the library can be steered into --
+    default, chain per lane, direct, sequential, state in global memory, strict memoised / direct: all bit-identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "fuzz_forms.py"), "32", "3"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    assert last.startswith("paths exercised:")
+    seen = eval(last.split(":", 1)[1])
+    assert {0, 1, 3, 6, 16, 17} <= set(seen), seen
+
+
 def test_value_parallel_form_equals_chain_per_lane(res_dir):
     """k_sweep_pw4 (4 lanes per chain, one per block of 4 values; path 6) and the chain-per-lane direct kernel (path 0) are
     the same process bit for bit: ObjectDetection_13 and random pairwise models with Card 2..16, evidence and floor-heavy
