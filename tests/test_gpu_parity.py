@@ -57,7 +57,9 @@ COND_ABS, COND_REL = 4e-10, 5e-5
                                      ("dv-rel_2.uai", True),             # 1200 variables, arity 4, 307 evidence variables
                                      ("dv-rel_3.uai", True),             # arity 10, 1024-entry tables (400 KB of tables: not LDS-resident)
                                      ("CSP_13.uai", False),              # Card 4, 31 factors on one variable
-                                     ("Promedus_17.uai", True)])         # 916 variables
+                                     ("Promedus_17.uai", True),          # 916 variables
+                                     ("Promedus_14.uai", True),          # up to 12 neighbours: the widest 64-byte packed records
+                                     ("CSP_11.uai", False)])             # pairwise, Card 4, 29 neighbours on one variable
 def test_conditional_matches_oracle(oracle, res_dir, name, ev):
     """a4-a8: gather + log-sum + stabilise/exp/floor + normalise (gibbs-simple.go:175-258)."""
     pm = uai_py.load(res_dir, name, ev)
@@ -216,6 +218,8 @@ def _thresholds_from_device(s, cards):
     ("Grids_11.uai", False, 128, 75, g.GR_FLAG_STATE_GLOBAL),           # chain state left in global memory, memoised tables
     ("ObjectDetection_13.uai", False, 70, 29, g.GR_FLAG_STATE_GLOBAL),  # ... direct pairwise path, ragged wavefront
     ("Pedigree_11.uai", True, 64, 37, g.GR_FLAG_STATE_GLOBAL | g.GR_FLAG_DIRECT),  # ... direct generic path, evidence
+    ("Promedus_14.uai", True, 64, 53, 0),  # 12 neighbours: packed records at their widest
+    ("CSP_11.uai", False, 64, 37, 0),      # pairwise Card-4 programs on the generic direct kernel
     ("dv-rel_3.uai", False, 64, 45, 0),  # 512 K threshold words: the 4-lane form with tables read from global memory
     ("Pedigree_11.uai", False, 64, 33, 0),  # 36 K threshold words, Card 3: generic memoised kernel, tables from global memory
     ("Grids_11.uai", False, 128, 97, g.GR_FLAG_SCAN_PER_CHAIN),       # strict mode: per-chain variable draws

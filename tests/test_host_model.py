@@ -101,7 +101,8 @@ def test_reader_errors():
                                      ("ObjectDetection_13.uai", False), ("Promedus_11.uai", True),
                                      ("Pedigree_11.uai", True), ("CSP_12.uai", False), ("dv-rel_1.uai", True),
                                      ("ObjectDetection_11.uai", False), ("Alchemy_11.uai", False), ("dv-rel_2.uai", True),
-                                     ("dv-rel_3.uai", True), ("CSP_13.uai", False), ("Promedus_17.uai", True)])
+                                     ("dv-rel_3.uai", True), ("CSP_13.uai", False), ("Promedus_17.uai", True),
+                                     ("Promedus_14.uai", True), ("CSP_11.uai", False)])
 def test_reader_matches_independent_twin(res_dir, name, ev):
     """The C++ reader and the independent Python reader agree on every fixture."""
     pm = uai_py.load(res_dir, name, ev)
