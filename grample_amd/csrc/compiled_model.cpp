@@ -91,9 +91,11 @@ VariantImage CompileVariant(const Model &m, const CompileLimits &lim) {
             }
             im.prog.push_back((uint32_t)tab_off);
             im.prog.push_back((uint32_t)oth.size());
+            im.max_others = std::max<uint32_t>(im.max_others, (uint32_t)oth.size());
             for (size_t k = 0; k < oth.size(); ++k) {
                 im.prog.push_back((uint32_t)f.Vars[oth[k]]);
                 im.prog.push_back((uint32_t)(ostride[k] * rowlen));
+                im.max_view_stride = std::max<uint32_t>(im.max_view_stride, (uint32_t)(ostride[k] * rowlen));
             }
         }
     }
@@ -176,6 +178,7 @@ VariantImage CompileVariant(const Model &m, const CompileLimits &lim) {
             if (cfgs > (1ull << 24)) { cfgs = (1ull << 24); im.cpt_ok = false; }
         }
         if (nb.size() > lim.max_cpt_neighbours) im.cpt_ok = false;
+        im.max_neighbours = std::max<uint32_t>(im.max_neighbours, (uint32_t)nb.size());
         im.cprog.push_back((uint32_t)var.Card | ((uint32_t)nb.size() << 8));
         im.cprog.push_back(hoff[v]);
         im.cprog.push_back((uint32_t)words);

@@ -47,6 +47,9 @@ struct VariantImage {
     //   last factor point at the all-zero row `zero_row` with stride 0, so the kernel needs no guards.
     std::vector<uint32_t> vprog, vprog_off;
     uint32_t zero_row = 0;          // float offset of an all-zero row (64 floats) at the end of `views`
+    uint32_t max_others = 0;        // largest (arity - 1) of any factor of a selectable variable
+    uint32_t max_view_stride = 0;   // largest view-table stride (floats) of an "other" scope variable
+    uint32_t max_neighbours = 0;    // largest blanket (free variables only, the variable itself excluded)
     std::vector<uint32_t> free_vars;// selectable variables: FixedVal < 0 and not Collapsed (sampler.go:146-156)
     bool cpt_ok = false;            // memoised path available
     std::vector<uint32_t> cprog;    // memoised programs

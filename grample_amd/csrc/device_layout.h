@@ -18,6 +18,7 @@ struct VariantDesc {
     uint32_t cpt_len;      // words
     uint32_t rec_base;     // records (kRecDwords each), into recs: one per entry of this group's free list
     uint32_t pprog_base;   // words, into pprogs (pairwise fixed-stride direct programs); pprog_off shares progoff_base
+    uint32_t dent_base, dent_len; // 16-byte units, into the factor entries of the step-parallel direct form (k_sweep_dir4)
     uint32_t vprog_base;   // words, into vprogs (value-parallel pairwise programs, k_sweep_pw4); vprog_off shares progoff_base
 };
 
@@ -104,6 +105,10 @@ struct FastParams {
     uint32_t plan_slots, plan_nfree_max; // k_scan_plan's LDS table: most neighbours of a variable, most selectable variables of a group
     uint32_t strict_state_off;   // k_sweep_strict with 4 waves per block: state regions of waves 1..3
     uint32_t strict_rec_stride;  // k_sweep_strict: record stride in LDS (rec_stride + 16 when it fits: bank spreading)
+    const uint32_t *dent;        // k_sweep_dir4: factor entries (16 bytes each); its step headers travel in recs_par
+    const float *views;          // k_sweep_dir4: the view-table pool (staged in LDS at dir_view_off when it fits)
+    uint32_t dir_view_off;       // k_sweep_dir4: LDS byte offset of the staged view tables
+    uint32_t dir_ent_off;        // k_sweep_dir4: LDS byte offset of the staged factor entries
     uint32_t par_stride;         // k_sweep_par4: bytes between the state rows of consecutive variables (80, or 64 for very large models)
     uint32_t tab_global;         // k_sweep_par4: threshold tables too large for LDS -- read from global memory (record word 2 = byte
                                  // offset inside the group's pool); records from global memory too (record mode 2)

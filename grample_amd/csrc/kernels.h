@@ -47,6 +47,8 @@ hipError_t launch_scan_plan(const FastParams &p, hipStream_t s);
 hipError_t launch_sweep_strict(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s);
 hipError_t launch_sweep_bin(const FastParams &p, int slots, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s);
 hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t lds, hipStream_t s);
+// step-parallel form of the direct conditional (sweep_dir4.hip): Card <= 4, arity <= 4, 64-chain blocks of 256 lanes
+hipError_t launch_sweep_dir4(const FastParams &p, int max_card, bool views_in_lds, bool entries_in_lds, uint32_t blocks, uint32_t lds, hipStream_t s);
 constexpr uint32_t kParStateStride = 80; // must match kParStride in sweep_bin.hip
 
 } // namespace gr

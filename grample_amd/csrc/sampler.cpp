@@ -112,6 +112,10 @@ struct gr_sampler {
     bool stg = false;                 // chain state stays in global memory (k_sweep<.., STG>): models whose state does not fit LDS
     bool pw4 = false;                 // value-parallel form of the direct path (k_sweep_pw4): pairwise, 8 < Card <= 16
     uint32_t pw4_hist_off = 0, pw4_lds = 0;
+    bool dir4 = false;                // step-parallel form of the direct conditional (k_sweep_dir4): Card <= 4, arity <= 4, blankets too large to memoise
+    bool dir4_vlds = false, dir4_elds = false; // ... with the view tables / the factor entries staged in LDS
+    uint32_t dir_hist_off = 0, dir_view_off = 0, dir_ent_off = 0, dir_lds = 0, dir_slots = 0;
+    DevBuf<uint32_t> d_dhdr, d_dent;  // ... its step headers (32 bytes per selectable variable) and factor entries (16 bytes per factor)
     DevBuf<unsigned short> d_scan_vars; // k_sweep_pw4: the variables of one launch (k_scan_vars), 8 bytes per quad and 64-chain group
     uint32_t pw4_plan_steps = 0;        // steps per k_sweep_pw4 launch (row length of d_scan_vars, multiple of 4)
     bool strict_fast = false;         // GR_FLAG_SCAN_PER_CHAIN on memoised tables (k_sweep_strict, the 4-lane form's LDS layout)
@@ -174,6 +178,39 @@ void gr_sampler::configure() {
         // measured on ObjectDetection_13: 1.9x the chain-per-lane form at 32 768 chains (2 wavefronts per SIMD instead of
         // one on half of the SIMDs), still 1.5x at 262 144 (fewer table bytes in flight per wavefront) -- so: whenever it fits
         pw4 = pw4_lds <= kLdsBudget;
+    }
+    // step-parallel direct form: blankets too large to memoise, at most 4 values per variable, arity <= 4, everything a
+    // 16-byte factor entry has to hold fits 16 bits (state rows 80 bytes apart: up to 819 variables; byte strides < 64 KiB)
+    dir4 = false;
+    if (!fast && !cpt && !stg && !pw4 && max_card <= 4 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE)) &&
+        o.fast_form != 1 && (o.n_chains % 64u) == 0 && (o.n_variants == 1 || cpv % 64u == 0) && !o.block_threads &&
+        (uint64_t)n_vars * kParStateStride < 65536u && H < 16384) {
+        bool ok = true;
+        uint32_t views_max = 0, ent_max = 0;
+        dir_slots = 1;
+        for (const auto &im : image) {
+            ok = ok && im.max_others <= 3u && (uint64_t)im.max_view_stride * 4u < 65536u && im.max_neighbours <= 255u;
+            views_max = std::max<uint32_t>(views_max, (uint32_t)im.views.size());
+            dir_slots = std::max(dir_slots, im.max_neighbours);
+            uint32_t n_ent = 0; // factor entries, every selectable variable's list padded to a multiple of 4
+            for (uint32_t v : im.free_vars) n_ent += ((im.prog[im.prog_off[v]] >> 16) + 3u) & ~3u;
+            ent_max = std::max(ent_max, n_ent);
+        }
+        dir_hist_off = ((uint32_t)n_vars * kParStateStride + 15u) & ~15u;
+        dir_view_off = dir_hist_off + (((uint32_t)H * 4u + 15u) & ~15u);
+        // view tables, then factor entries, go to LDS while that still leaves a CU two blocks (or all it needs);
+        // what does not is read from global memory / L2
+        const uint32_t need = std::min<uint32_t>((o.n_chains / 64u + 255u) / 256u, 2u);
+        const uint32_t with_views = dir_view_off + views_max * 4u;
+        dir4_vlds = with_views <= kLdsBudget && kLdsBudget / with_views >= need;
+        dir_ent_off = dir4_vlds ? with_views : dir_view_off;
+        const uint32_t with_ent = dir_ent_off + ent_max * 16u;
+        dir4_elds = with_ent <= kLdsBudget && kLdsBudget / with_ent >= need;
+        dir_lds = dir4_elds ? with_ent : dir_ent_off;
+        // the scan-plan kernel keeps every selectable variable's neighbour list in LDS (u16 each)
+        uint32_t nfree_max = 1;
+        for (const auto &im : image) nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)im.free_vars.size());
+        dir4 = ok && dir_lds <= kLdsBudget && (uint64_t)nfree_max * (2u + dir_slots) * 2u <= 64u * 1024u;
     }
 }
 
@@ -464,6 +501,51 @@ void gr_sampler::rebuild() {
         plan_steps = (uint32_t)std::max<uint64_t>(ps, 16);
         d_plan.alloc((size_t)waves * plan_steps + 16);
     }
+    if (dir4) {
+        // step headers + factor entries of the direct 4-lane form, from the generic programs (compiled_model.hpp)
+        std::vector<uint32_t> hdr, ent;
+        uint32_t rec_count = 0;
+        for (uint32_t g = 0; g < o.n_variants; ++g) {
+            const VariantImage &im = image[g];
+            h_variants[g].rec_base = rec_count;
+            rec_count += (uint32_t)im.free_vars.size();
+            h_variants[g].dent_base = (uint32_t)(ent.size() / 4u);
+            const uint32_t vbase = dir4_vlds ? dir_view_off : 0u; // views staged in LDS: entries carry absolute LDS addresses
+            for (uint32_t v : im.free_vars) {
+                const uint32_t *pg = im.prog.data() + im.prog_off[v];
+                const uint32_t C = pg[0] & 0xffu, nf = pg[0] >> 16, n_ent = (nf + 3u) & ~3u;
+                // entries staged in LDS: absolute LDS address of the variable's list; else byte offset into the entry pool
+                const uint32_t eoff = dir4_elds ? dir_ent_off + ((uint32_t)(ent.size() / 4u) - h_variants[g].dent_base) * 16u : (uint32_t)ent.size() * 4u;
+                const uint32_t h8[8] = {v * kParStateStride, dir_hist_off + pg[1] * 4u, eoff, n_ent | (C << 16), 0, 0, 0, 0};
+                hdr.insert(hdr.end(), h8, h8 + 8);
+                const uint32_t *q = pg + 2;
+                const uint32_t own = v * kParStateStride;
+                for (uint32_t f = 0; f < n_ent; ++f) {
+                    uint32_t toff = im.zero_row, row[3] = {own, own, own}, st[3] = {0, 0, 0}; // padding: the all-zero row, stride 0
+                    if (f < nf) {
+                        const uint32_t no = q[1];
+                        toff = q[0];
+                        for (uint32_t k = 0; k < no && k < 3; ++k) { row[k] = q[2 + 2 * k] * kParStateStride; st[k] = q[3 + 2 * k] * 4u; }
+                        q += 2 + 2 * no;
+                    }
+                    ent.push_back(vbase + toff * 4u);
+                    ent.push_back(row[0] | (row[1] << 16));
+                    ent.push_back(row[2] | (st[0] << 16));
+                    ent.push_back(st[1] | (st[2] << 16));
+                }
+            }
+            h_variants[g].dent_len = (uint32_t)(ent.size() / 4u) - h_variants[g].dent_base;
+        }
+        ent.resize(ent.size() + 4, 0);
+        d_variants.upload(h_variants, stream); // now with rec_base
+        d_dhdr.upload(hdr, stream);
+        d_dent.upload(ent, stream);
+        const uint64_t waves = o.n_chains / 64u;
+        uint64_t ps = (256ull << 20) / (waves * 4ull); // <= 256 MiB of plan per launch
+        ps = std::min<uint64_t>(ps, kMaxStepsPerLaunch) & ~15ull;
+        plan_steps = (uint32_t)std::max<uint64_t>(ps, 16);
+        d_plan.alloc((size_t)waves * plan_steps + 16);
+    }
     sync();
     dirty = false;
 }
@@ -550,7 +632,38 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         T = 256; blocks = (act + 255) / 256;
         generic(n_total);
     };
-    if (!fast || (par_tabg && cur_log)) { // (the global-table 4-lane form is not built with the draw log)
+    if (dir4 && !fast && !cur_log) {
+        // quad-unaligned head and tail go through the generic kernel (bit-identical streams), the rest in launches of
+        // k_scan_plan + k_sweep_dir4 (16 steps per inner iteration)
+        FastParams f{};
+        f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p;
+        f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p; f.plan_pitch = plan_steps;
+        f.rec_stride = 32; f.recs_par = d_dhdr.p; f.dent = d_dent.p; f.views = d_views.p; f.dir_view_off = dir_view_off; f.dir_ent_off = dir_ent_off;
+        if (!d_err.p) {
+            d_err.alloc(1);
+            hip_check(hipMemsetAsync(d_err.p, 0, sizeof(uint32_t), stream), "hipMemset");
+        }
+        f.err = d_err.p;
+        f.plan_slots = dir_slots;
+        f.plan_nfree_max = 1;
+        for (const auto &im : image) f.plan_nfree_max = std::max<uint32_t>(f.plan_nfree_max, (uint32_t)im.free_vars.size());
+        f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = act; f.pitch = pitch; f.chains_per_variant = cpv;
+        f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
+        f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi;
+        f.counting = p.counting; f.par_hist_off = dir_hist_off; f.par_stride = kParStateStride;
+        uint64_t left = updates;
+        const uint64_t head = std::min<uint64_t>(left, (16 - (step % 16)) % 16);
+        if (head) { generic_small(head); left -= head; }
+        while (left >= 16) {
+            const uint32_t n = (uint32_t)std::min<uint64_t>(left - left % 16, plan_steps);
+            f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
+            f.n_steps = n;
+            hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
+            hip_check(launch_sweep_dir4(f, max_card, dir4_vlds, dir4_elds, act / 64u, dir_lds, stream), "k_sweep_dir4 launch");
+            step += n; left -= n; launches_last++;
+        }
+        if (left) generic_small(left);
+    } else if (!fast || (par_tabg && cur_log)) { // (the global-table 4-lane form is not built with the draw log)
         generic(updates);
     } else {
         // quad-unaligned head and tail go through the generic kernel (bit-identical streams)
@@ -1539,9 +1652,9 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         if (!s || !out || out->struct_size != sizeof(gr_sampler_info)) throw Error(GR_E_INVALID, "bad gr_sampler_info");
         if (s->dirty) { s->use(); s->configure(); }
         out->block_threads = s->T; out->n_blocks = s->blocks;
-        out->lds_bytes = s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->lds; // of the kernel that actually runs
+        out->lds_bytes = s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->dir4 ? s->dir_lds : s->lds; // of the kernel that actually runs
         if (s->fast && s->par) { out->block_threads = s->strict_fast ? s->T : 256u; out->n_blocks = s->active_chains() / 64u; }
-        out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
+        out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

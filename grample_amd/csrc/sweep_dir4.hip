@@ -1,0 +1,239 @@
+// K1, step-parallel form of the DIRECT conditional (k_sweep_dir4): 4 lanes per chain, one per step of a quad, for models
+// whose blankets are too large to memoise and whose variables have at most 4 values (CSP: Card 2..4 with up to 31 factors
+// on a variable, Alchemy: binary with blankets of up to 59 variables).
+//
+// The generic direct kernel walks the updated variable's program on the scalar unit -- fine with many wavefronts, but at the
+// BASELINE sizes (32 768 chains = 512 chain-per-lane wavefronts) half of the chip's SIMDs have no wavefront and the others a
+// lone one that issues an instruction every ~10 cycles: ~900 instructions per 64-chain step on CSP_13, most of them scalar
+// address work and branches.  Here the k_sweep_par4 shape is used instead (sweep_bin.hip): a 256-lane block owns the 64
+// chains of one scan group, lane = step slot * 16 + chain, the scan plan (k_scan_plan) names each step's variable and its
+// dependency level inside the quad, steps that do not commute are re-evaluated level by level -- but a step's conditional
+// is EVALUATED, not looked up: the lane walks the variable's factor list (16-byte entries {view offset, other variables'
+// state rows, strides}, read with row-uniform vector loads), gathers the neighbour states from LDS, sums the view rows in
+// Model.Funcs order and runs cond.h itself.  Every lane does exactly the arithmetic one lane of the generic kernel does, in
+// the same order: bit-identical results.  32 768 chains are 2 048 wavefronts and 4 steps of every chain are in flight.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "cond.h"
+#include "device_layout.h"
+#include "kernels.h"
+#include "philox.h"
+
+namespace gr {
+
+namespace {
+
+__device__ __forceinline__ uint32_t uni_d(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
+typedef __attribute__((address_space(3))) uint32_t lds_u32d_t;
+__device__ __forceinline__ uint32_t lds_addr_d(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p; }
+__device__ __forceinline__ lds_u32d_t *lds_at_d(uint32_t addr) { return (lds_u32d_t *)(uintptr_t)addr; }
+
+} // namespace
+
+// Step header (32 bytes, one per selectable variable, addressed by the plan word like a k_sweep_par4 record):
+//   w0 state-row byte offset (var * 80)     w1 absolute LDS byte address of the variable's histogram slots
+//   w2 byte offset of its factor entries (absolute LDS address when they are staged)
+//   w3 number of entries (factors padded to a multiple of 4 with entries that read an all-zero row) | Card << 16
+// Factor entry (16 bytes): {view-table byte offset (LDS address when the views are staged, else offset into the group's
+// view pool), row1 | row2 << 16, row3 | stride1 << 16, stride2 | stride3 << 16} -- the state rows of up to three other
+// scope variables and their byte strides in the view table; unused slots name the variable's own row with stride 0.
+// VLDS / ELDS: the group's view tables / factor entries are staged in LDS (else read from global memory through L1/L2).
+template <int MAXC, bool VLDS, bool ELDS, bool COUNT>
+__global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t j = lane >> 4;                    // step slot inside the quad
+    const uint32_t cb = wave * 16u + (lane & 15u);   // chain inside the block
+    const uint32_t chain = blockIdx.x * 64u + cb;
+    const uint32_t variant = (blockIdx.x * 64u) / p.chains_per_variant;
+    const VariantDesc vd = p.variants[variant];
+    {
+        if constexpr (VLDS) { // this group's view tables
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.views + vd.views_base);
+            uint4 *dst = reinterpret_cast<uint4 *>(lds + p.dir_view_off);
+            for (uint32_t i = tid; i < (vd.views_len >> 2); i += 256) dst[i] = src[i];
+        }
+        if constexpr (ELDS) { // ... and its factor entries
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.dent) + vd.dent_base;
+            uint4 *dst = reinterpret_cast<uint4 *>(lds + p.dir_ent_off);
+            for (uint32_t i = tid; i < vd.dent_len; i += 256) dst[i] = src[i];
+        }
+        for (uint32_t v = j; v < p.n_vars; v += 4) lds[v * p.par_stride + cb] = p.state[(size_t)v * p.pitch + chain];
+        uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
+        for (uint32_t i = tid; i < p.H; i += 256) h[i] = 0;
+    }
+    __syncthreads();
+    // headers and entries hold offsets into the dynamic LDS array, used as absolute LDS addresses: it must start at 0 (no
+    // static LDS in this kernel); fail loudly otherwise (error flag -> GR_E_STATE), like k_sweep_par4
+    if (lds_addr_d(lds) != 0u) {
+        if (threadIdx.x == 0) atomicOr(p.err, 1u);
+        return;
+    }
+
+    const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
+    const uint64_t q0 = (((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2;
+    const uint32_t nq = p.n_steps >> 2; // multiple of 4
+    const unsigned char *lds_c = lds + cb;
+    const unsigned char *hdr_g = reinterpret_cast<const unsigned char *>(p.recs_par);
+    const unsigned char *ent_g = reinterpret_cast<const unsigned char *>(p.dent);
+    const unsigned char *views_g = reinterpret_cast<const unsigned char *>(p.views + vd.views_base);
+    const uint32_t *gplan_w = p.plan + (size_t)blockIdx.x * p.plan_pitch + j;
+    const bool tail = (lane & 15u) == 15u;
+
+    // headers of the NEXT iteration in flight while the current one runs; plan words two iterations ahead
+    uint32_t pwn[4] = {0, 0, 0, 0}, pwa[4] = {0, 0, 0, 0};
+    uint4 hn[4];
+    auto prefetch_plan = [&](const uint32_t gnext) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pwa[k] = gplan_w[(size_t)min(gnext + (uint32_t)k, nq - 1u) * 4u]; // never past the plan
+    };
+    auto prefetch = [&]() {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pwn[k] = pwa[k];
+            hn[k] = *reinterpret_cast<const uint4 *>(hdr_g + (pwn[k] & ~31u));
+        }
+    };
+    prefetch_plan(0); prefetch(); prefetch_plan(4);
+
+    // the conditional of one step, evaluated from the factor tables (gibbs-simple.go:175-258): gather, log sums in
+    // Model.Funcs order, cond.h.  The loop runs to the largest factor count among the wavefront's four step slots.
+    auto eval = [&](const uint4 &h, const uint32_t u) -> uint32_t {
+        const uint32_t nf = h.w & 0xffffu;
+        const int C = (int)(h.w >> 16);
+        const uint32_t n01 = max((uint32_t)__builtin_amdgcn_readlane((int)nf, 0), (uint32_t)__builtin_amdgcn_readlane((int)nf, 16));
+        const uint32_t n23 = max((uint32_t)__builtin_amdgcn_readlane((int)nf, 32), (uint32_t)__builtin_amdgcn_readlane((int)nf, 48));
+        const uint32_t nmax = max(n01, n23);
+        float w[MAXC];
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) w[i] = 0.f;
+        // four factors per trip: their entries, then their 12 neighbour bytes, then their 4 view rows are each requested
+        // together (one memory round trip per stage and trip instead of three per factor); summed in factor order
+        for (uint32_t f = 0; f < nmax; f += 4) {
+            if (f < nf) {
+                uint4 e[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (ELDS) e[i] = *reinterpret_cast<const uint4 *>(lds + h.z + 16u * (f + (uint32_t)i));
+                    else e[i] = *reinterpret_cast<const uint4 *>(ent_g + h.z + 16u * (f + (uint32_t)i));
+                }
+                uint32_t off[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t x1 = lds_c[e[i].y & 0xffffu], x2 = lds_c[e[i].y >> 16], x3 = lds_c[e[i].z & 0xffffu];
+                    off[i] = e[i].x + __umul24(x1, e[i].z >> 16) + __umul24(x2, e[i].w & 0xffffu) + __umul24(x3, e[i].w >> 16);
+                }
+                if constexpr (MAXC <= 2) {
+                    float2 r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (VLDS) r[i] = *reinterpret_cast<const float2 *>(lds + off[i]);
+                        else r[i] = *reinterpret_cast<const float2 *>(views_g + off[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { w[0] += r[i].x; w[1] += r[i].y; }
+                } else {
+                    float4 r[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if constexpr (VLDS) r[i] = *reinterpret_cast<const float4 *>(lds + off[i]);
+                        else r[i] = *reinterpret_cast<const float4 *>(views_g + off[i]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { w[0] += r[i].x; w[1] += r[i].y; w[2] += r[i].z; w[3] += r[i].w; }
+                }
+            }
+        }
+        double cum[MAXC > 1 ? MAXC - 1 : 1], s;
+        cumulative<MAXC>(w, C, cum, s);
+        return pick<MAXC>(cum, s, C, u);
+    };
+
+    for (uint32_t g0 = 0; g0 < nq; g0 += 4) {
+        // draws: my Philox call is quad g0 + j; a 4x4 transpose (step slots x words) with gfx950's lane swaps leaves lane
+        // (j, c) with word j of quads g0 .. g0 + 3 (see k_sweep_par4)
+        const uint64_t q = q0 + g0 + j;
+        const u32x4 W = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
+        uint32_t U[4];
+        {
+            const auto a = __builtin_amdgcn_permlane32_swap(W.x, W.z, false, false);
+            const auto b = __builtin_amdgcn_permlane32_swap(W.y, W.w, false, false);
+            const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+            const auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+            U[0] = c[0]; U[1] = c[1]; U[2] = d[0]; U[3] = d[1];
+        }
+        uint32_t pw[4];
+        uint4 hq[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { pw[k] = pwn[k]; hq[k] = hn[k]; }
+        prefetch(); prefetch_plan(g0 + 8u);
+#pragma unroll 1
+        for (int k = 0; k < 4; ++k) {
+            const uint4 h = k == 0 ? hq[0] : k == 1 ? hq[1] : k == 2 ? hq[2] : hq[3];
+            const uint32_t pwk = k == 0 ? pw[0] : k == 1 ? pw[1] : k == 2 ? pw[2] : pw[3];
+            const uint32_t u = k == 0 ? U[0] : k == 1 ? U[1] : k == 2 ? U[2] : U[3];
+            const uint32_t lv = (pwk >> 1) & 3u;
+            const uint32_t maxlv = uni_d(pwk >> 3) & 3u;
+            unsigned char *wr = lds + h.x + cb;
+            uint32_t val = eval(h, u);
+            if (lv == 0) *wr = (unsigned char)val;
+            for (uint32_t pass = 1; pass <= maxlv; ++pass) { // steps that do not commute: re-evaluate after the lower levels committed
+                const uint32_t v2 = eval(h, u);
+                if (lv == pass) { *wr = (unsigned char)v2; val = v2; }
+            }
+            if constexpr (COUNT) {
+                if constexpr (MAXC <= 2) {
+                    // ones of the step slot's 16 draws: prefix popcount of the draw mask minus the prefix at the end of the
+                    // previous DPP row, valid in lane 15 of every row (k_sweep_par4's count)
+                    const unsigned long long drawn = __ballot(val != 0u);
+                    const int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(drawn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)drawn, 0u)) + (int)val;
+                    const int s1 = incl - __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xe, 0xf, false);
+                    if (tail) {
+                        lds_u32d_t *hp = lds_at_d(h.y);
+                        __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_fetch_add(hp + 1, (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                } else {
+                    __hip_atomic_fetch_add(lds_at_d(h.y + 4u * val), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    }
+
+    for (uint32_t v = j; v < p.n_vars; v += 4) p.state[(size_t)v * p.pitch + chain] = lds[v * p.par_stride + cb];
+    if constexpr (COUNT) {
+        __syncthreads();
+        const uint32_t *h = reinterpret_cast<const uint32_t *>(lds + p.par_hist_off);
+        unsigned long long *gc = p.counts + (size_t)variant * p.H;
+        for (uint32_t i = tid; i < p.H; i += 256) {
+            const uint32_t c = h[i];
+            if (c) atomicAdd(&gc[i], (unsigned long long)c);
+        }
+    }
+}
+
+template <int MAXC, bool VLDS, bool ELDS>
+static hipError_t launch_dir4_t(const FastParams &p, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
+        return hipGetLastError();
+    };
+    return p.counting ? go(&k_sweep_dir4<MAXC, VLDS, ELDS, true>) : go(&k_sweep_dir4<MAXC, VLDS, ELDS, false>);
+}
+
+hipError_t launch_sweep_dir4(const FastParams &p, int max_card, bool views_in_lds, bool entries_in_lds, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    if (p.log || max_card > 4) return hipErrorInvalidValue;
+    auto pick = [&](auto mc) -> hipError_t {
+        constexpr int MC = decltype(mc)::value;
+        if (views_in_lds) return entries_in_lds ? launch_dir4_t<MC, true, true>(p, blocks, lds, s) : launch_dir4_t<MC, true, false>(p, blocks, lds, s);
+        return entries_in_lds ? launch_dir4_t<MC, false, true>(p, blocks, lds, s) : launch_dir4_t<MC, false, false>(p, blocks, lds, s);
+    };
+    return max_card <= 2 ? pick(std::integral_constant<int, 2>{}) : pick(std::integral_constant<int, 4>{});
+}
+
+} // namespace gr
