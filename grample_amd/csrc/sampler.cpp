@@ -182,7 +182,8 @@ void gr_sampler::configure() {
     // step-parallel direct form: blankets too large to memoise, at most 4 values per variable, arity <= 4, everything a
     // 16-byte factor entry has to hold fits 16 bits (state rows 80 bytes apart: up to 819 variables; byte strides < 64 KiB)
     dir4 = false;
-    if (!fast && !cpt && !stg && !pw4 && max_card <= 4 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE)) &&
+    // (GR_FLAG_DIRECT keeps the generic kernel: it is the cross-check every other form is compared with)
+    if (!fast && !cpt && !stg && !pw4 && max_card <= 4 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE | GR_FLAG_DIRECT)) &&
         o.fast_form != 1 && (o.n_chains % 64u) == 0 && (o.n_variants == 1 || cpv % 64u == 0) && !o.block_threads &&
         (uint64_t)n_vars * kParStateStride < 65536u && H < 16384) {
         bool ok = true;
@@ -198,11 +199,12 @@ void gr_sampler::configure() {
         }
         dir_hist_off = ((uint32_t)n_vars * kParStateStride + 15u) & ~15u;
         dir_view_off = dir_hist_off + (((uint32_t)H * 4u + 15u) & ~15u);
-        // view tables, then factor entries, go to LDS while that still leaves a CU two blocks (or all it needs);
-        // what does not is read from global memory / L2
+        // Factor entries go to LDS while that still leaves a CU two blocks (or all it needs).  View tables only for binary
+        // models (8-byte rows): with 16-byte rows the per-lane row reads are what saturates the LDS pipe, and the otherwise
+        // idle vector-memory path serves them better from L1/L2 (CSP_13: 1.85e10 with the views in LDS, 2.93e10 without).
         const uint32_t need = std::min<uint32_t>((o.n_chains / 64u + 255u) / 256u, 2u);
         const uint32_t with_views = dir_view_off + views_max * 4u;
-        dir4_vlds = with_views <= kLdsBudget && kLdsBudget / with_views >= need;
+        dir4_vlds = max_card <= 2 && with_views <= kLdsBudget && kLdsBudget / with_views >= need;
         dir_ent_off = dir4_vlds ? with_views : dir_view_off;
         const uint32_t with_ent = dir_ent_off + ent_max * 16u;
         dir4_elds = with_ent <= kLdsBudget && kLdsBudget / with_ent >= need;

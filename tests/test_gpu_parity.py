@@ -353,7 +353,23 @@ def test_cross_form_fuzz():
     last = out.stdout.strip().splitlines()[-1]
     assert last.startswith("paths exercised:")
     seen = eval(last.split(":", 1)[1])
-    assert {0, 1, 3, 6, 16, 17} <= set(seen), seen
+    assert {0, 1, 3, 6, 8, 16, 17} <= set(seen), seen
+
+
+@pytest.mark.parametrize("name", ["CSP_12.uai", "CSP_13.uai", "CSP_11.uai", "Alchemy_11.uai"])
+def test_step_parallel_direct_form_equals_generic(res_dir, name):
+    """k_sweep_dir4 (path 8: 4 lanes per chain, the conditional evaluated from the factor tables by each lane) on the dense
+    small-Card fixtures -- blankets of up to 59 variables, up to 31 factors on a variable, arity 3, Card 2..4 -- is the
+    same process as the generic direct kernel (GR_FLAG_DIRECT), bit for bit; quad-unaligned launches, 64-bit chain ids."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    out = []
+    for flags in (0, g.GR_FLAG_DIRECT):
+        s = g.HIPChains(m, 1024, seed=13, chain_offset=(1 << 34) + 128, flags=flags)
+        s.BurnIn(45); s.Advance(211); s.Advance(64)
+        out.append((s.info()["path"], s.counts(), s.checkpoint()["states"]))
+    assert out[0][0] == 8 and out[1][0] == 0
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert int(out[0][1].sum()) == 1024 * 275
 
 
 def test_value_parallel_form_equals_chain_per_lane(res_dir):
