@@ -183,7 +183,11 @@ void gr_sampler::configure() {
     // 16-byte factor entry has to hold fits 16 bits (state rows 80 bytes apart: up to 819 variables; byte strides < 64 KiB)
     dir4 = false;
     // (GR_FLAG_DIRECT keeps the generic kernel: it is the cross-check every other form is compared with)
-    if (!fast && !cpt && !stg && !pw4 && max_card <= 4 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE | GR_FLAG_DIRECT)) &&
+    // ... and models that are memoisable but not binary (the generic memoised kernel is chain-per-lane too: Pedigree_11 without
+    // evidence 3.5e10 there, 9.3e10 here), unless they are so small that most quads are one dependency chain (sample.uai)
+    uint32_t nfree_min = 0xffffffffu;
+    for (const auto &im : image) nfree_min = std::min<uint32_t>(nfree_min, (uint32_t)im.free_vars.size());
+    if (!fast && (!cpt || nfree_min >= 16u) && !stg && !pw4 && max_card <= 4 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE | GR_FLAG_DIRECT)) &&
         o.fast_form != 1 && (o.n_chains % 64u) == 0 && (o.n_variants == 1 || cpv % 64u == 0) && !o.block_threads &&
         (uint64_t)n_vars * kParStateStride < 65536u && H < 16384) {
         bool ok = true;

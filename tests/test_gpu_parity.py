@@ -221,7 +221,7 @@ def _thresholds_from_device(s, cards):
     ("Promedus_14.uai", True, 64, 53, 0),  # 12 neighbours: packed records at their widest
     ("CSP_11.uai", False, 64, 37, 0),      # pairwise Card-4 programs on the generic direct kernel
     ("dv-rel_3.uai", False, 64, 45, 0),  # 512 K threshold words: the 4-lane form with tables read from global memory
-    ("Pedigree_11.uai", False, 64, 33, 0),  # 36 K threshold words, Card 3: generic memoised kernel, tables from global memory
+    ("Pedigree_11.uai", False, 64, 33, 0),  # Card 3, arity 4, memoisable: the step-parallel direct kernel (path 8)
     ("Grids_11.uai", False, 128, 97, g.GR_FLAG_SCAN_PER_CHAIN),       # strict mode: per-chain variable draws
     ("ObjectDetection_13.uai", False, 64, 33, g.GR_FLAG_SCAN_PER_CHAIN),
     ("Pedigree_11.uai", True, 70, 45, g.GR_FLAG_SCAN_PER_CHAIN),
@@ -287,7 +287,8 @@ def test_global_threshold_tables_equal_direct(res_dir, name, ev, path):
     m = g.Model.NewModelFromFile(os.path.join(res_dir, name), ev)
     out = []
     for flags in (0, g.GR_FLAG_DIRECT):
-        s = g.HIPChains(m, 1024, seed=3, flags=flags, chain_offset=64)
+        # (path 1 = the chain-per-lane memoised kernel: asked for explicitly, the default for a non-binary model is path 8)
+        s = g.HIPChains(m, 1024, seed=3, flags=flags, chain_offset=64, fast_form=1 if path == 1 else 0)
         s.BurnIn(50); s.Advance(203); s.Advance(64)
         i = s.info()
         out.append((i["path"], i["tables_in_lds"], s.counts(), s.checkpoint()["states"]))
