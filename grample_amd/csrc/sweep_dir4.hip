@@ -101,8 +101,9 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
 
     // the conditional of one step, evaluated from the factor tables (gibbs-simple.go:175-258): gather, log sums in
     // Model.Funcs order, cond.h.  The loop runs to the largest factor count among the wavefront's four step slots.
-    auto eval = [&](const uint4 &h, const uint32_t u) -> uint32_t {
-        const uint32_t nf = h.w & 0xffffu;
+    // `mine`: only the step slots whose turn it is take part (the others walk no factors: no LDS traffic for them)
+    auto eval = [&](const uint4 &h, const uint32_t u, const bool mine) -> uint32_t {
+        const uint32_t nf = mine ? h.w & 0xffffu : 0u;
         const int C = (int)(h.w >> 16);
         const uint32_t n01 = max((uint32_t)__builtin_amdgcn_readlane((int)nf, 0), (uint32_t)__builtin_amdgcn_readlane((int)nf, 16));
         const uint32_t n23 = max((uint32_t)__builtin_amdgcn_readlane((int)nf, 32), (uint32_t)__builtin_amdgcn_readlane((int)nf, 48));
@@ -178,11 +179,13 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
             const uint32_t lv = (pwk >> 1) & 3u;
             const uint32_t maxlv = uni_d(pwk >> 3) & 3u;
             unsigned char *wr = lds + h.x + cb;
-            uint32_t val = eval(h, u);
-            if (lv == 0) *wr = (unsigned char)val;
-            for (uint32_t pass = 1; pass <= maxlv; ++pass) { // steps that do not commute: re-evaluate after the lower levels committed
-                const uint32_t v2 = eval(h, u);
-                if (lv == pass) { *wr = (unsigned char)v2; val = v2; }
+            // level by level: a step is evaluated exactly once, in the pass of its own dependency level, after the steps of the
+            // lower levels (the ones it does not commute with) have committed
+            uint32_t val = 0;
+            for (uint32_t pass = 0; pass <= maxlv; ++pass) {
+                const bool mine = lv == pass;
+                const uint32_t v2 = eval(h, u, mine);
+                if (mine) { *wr = (unsigned char)v2; val = v2; }
             }
             if constexpr (COUNT) {
                 if constexpr (MAXC <= 2) {
