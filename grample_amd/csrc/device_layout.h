@@ -98,6 +98,7 @@ struct FastParams {
     unsigned char *log;          // optional draw log, see SweepParams (4-lane form: one row per wavefront = 16 chains)
     uint32_t log_pitch, log_off;
     const uint32_t *limit;       // see SweepParams::limit (window offset of the launch = log_off)
+    uint32_t log_vals;           // bytes per logged step (k_sweep_dir4: 1 = the number of ones, else max Card: one count per value)
     const uint32_t *recs_par;
     uint32_t par_hist_off, par_tab_off, par_rec_off, par_plan_off, par_scr_off;
     uint32_t *err;               // device error word (bit 0: the dynamic LDS array does not start at LDS address 0)

@@ -638,7 +638,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         T = 256; blocks = (act + 255) / 256;
         generic(n_total);
     };
-    if (dir4 && !fast && !cur_log) {
+    if (dir4 && !fast) {
         // quad-unaligned head and tail go through the generic kernel (bit-identical streams), the rest in launches of
         // k_scan_plan + k_sweep_dir4 (16 steps per inner iteration)
         FastParams f{};
@@ -664,12 +664,13 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             const uint32_t n = (uint32_t)std::min<uint64_t>(left - left % 16, plan_steps);
             f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
             f.n_steps = n;
+            f.log = cur_log; f.log_pitch = cur_log_pitch; f.log_off = (uint32_t)(step - cur_log_step0); f.limit = cur_limit; f.log_vals = cur_log_vals;
             hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
             hip_check(launch_sweep_dir4(f, max_card, dir4_vlds, dir4_elds, act / 64u, dir_lds, stream), "k_sweep_dir4 launch");
             step += n; left -= n; launches_last++;
         }
         if (left) generic_small(left);
-    } else if (!fast || (par_tabg && cur_log)) { // (the global-table 4-lane form is not built with the draw log)
+    } else if (!fast) {
         generic(updates);
     } else {
         // quad-unaligned head and tail go through the generic kernel (bit-identical streams)
@@ -1408,7 +1409,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         bool binary = true;
         for (uint32_t g = 0; g < (s->o.n_variants > 1 ? s->n_active : 1u) && binary; ++g)
             for (uint32_t v : s->image[g].free_vars) binary = binary && s->card[v] == 2;
-        const uint32_t rows = s->par ? 4u : 1u;
+        const uint32_t rows = (s->par || s->dir4) ? 4u : 1u; // the 4-lane forms log one row per wavefront (16 chains)
         const uint32_t log_vals = binary ? 1u : (uint32_t)s->max_card;
         const uint64_t pitch = (L * log_vals + 15u) & ~15ull;
         const bool logging = (binary || !s->fast) && pitch <= 0xfffffff0ull && (uint64_t)n_groups * rows * pitch <= (16ull << 30);

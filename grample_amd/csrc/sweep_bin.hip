@@ -725,8 +725,8 @@ static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t ld
     // where the records come from (p.par_recmode: 0..2 forced, else by occupancy): with fewer than 3 wavefronts per SIMD
     // (256 CUs x 4 SIMDs, 4 wavefronts per block) the kernel is latency-bound -> LDS records fetched together; with more it
     // sits on the LDS pipe -> records from global memory, prefetched an iteration ahead
-    if (p.tab_global) // thresholds from global memory: record mode 2, no draw log (the host runs logged windows on the generic kernel)
-        return p.log ? hipErrorInvalidValue : !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 2, true>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 2, true>);
+    if (p.tab_global) // thresholds from global memory: record mode 2
+        return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 2, true>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 2, true>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 2, true>);
     const int rm = p.par_recmode <= 2u ? (int)p.par_recmode : (blocks * 4u < 3u * 1024u ? 1 : 2);
     if (rm == 2) return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 2>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 2>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 2>);
     if (rm == 1) return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 1>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 1>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 1>);

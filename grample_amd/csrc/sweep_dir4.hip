@@ -41,8 +41,10 @@ __device__ __forceinline__ lds_u32d_t *lds_at_d(uint32_t addr) { return (lds_u32
 // view pool), row1 | row2 << 16, row3 | stride1 << 16, stride2 | stride3 << 16} -- the state rows of up to three other
 // scope variables and their byte strides in the view table; unused slots name the variable's own row with stride 0.
 // VLDS / ELDS: the group's view tables / factor entries are staged in LDS (else read from global memory through L1/L2).
-template <int MAXC, bool VLDS, bool ELDS, bool COUNT>
+// MODE 0: burn-in, 1: count, 2: count + draw log and per-group stopping time (gr_advance_chain; SweepParams::log / limit)
+template <int MAXC, bool VLDS, bool ELDS, int MODE>
 __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
+    constexpr bool COUNT = MODE != 0, LOG = MODE == 2;
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t j = lane >> 4;                    // step slot inside the quad
@@ -82,6 +84,15 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
     const unsigned char *views_g = reinterpret_cast<const unsigned char *>(p.views + vd.views_base);
     const uint32_t *gplan_w = p.plan + (size_t)blockIdx.x * p.plan_pitch + j;
     const bool tail = (lane & 15u) == 15u;
+    // draw log: one row per wavefront (the 16 chains of a step slot), log_vals bytes per step -- the number of ones, or one
+    // count per value; a group executes only the first `lim` steps of the window (its own AdvanceChain stopping time)
+    unsigned char *logrow = LOG && p.log ? p.log + (size_t)(blockIdx.x * 4u + wave) * p.log_pitch + (size_t)p.log_off * p.log_vals : nullptr;
+    uint32_t lim = 0xffffffffu;
+    if constexpr (LOG)
+        if (p.limit) {
+            const uint32_t t = p.limit[blockIdx.x];
+            lim = t > p.log_off ? t - p.log_off : 0u;
+        }
 
     // headers of the NEXT iteration in flight while the current one runs; plan words two iterations ahead
     uint32_t pwn[4] = {0, 0, 0, 0}, pwa[4] = {0, 0, 0, 0};
@@ -181,26 +192,38 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
             unsigned char *wr = lds + h.x + cb;
             // level by level: a step is evaluated exactly once, in the pass of its own dependency level, after the steps of the
             // lower levels (the ones it does not commute with) have committed
+            const uint32_t sidx = (g0 + (uint32_t)k) * 4u + j;     // step index inside this launch
+            const bool runs = !LOG || sidx < lim;                   // (limits are even: a quad is cut between its steps 1 and 2 at most)
             uint32_t val = 0;
             for (uint32_t pass = 0; pass <= maxlv; ++pass) {
-                const bool mine = lv == pass;
+                const bool mine = lv == pass && runs;
                 const uint32_t v2 = eval(h, u, mine);
                 if (mine) { *wr = (unsigned char)v2; val = v2; }
             }
             if constexpr (COUNT) {
+                if (LOG && uni_d(sidx & ~3u) >= lim) continue;      // the whole quad is past the group's stopping time
                 if constexpr (MAXC <= 2) {
                     // ones of the step slot's 16 draws: prefix popcount of the draw mask minus the prefix at the end of the
                     // previous DPP row, valid in lane 15 of every row (k_sweep_par4's count)
                     const unsigned long long drawn = __ballot(val != 0u);
                     const int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(drawn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)drawn, 0u)) + (int)val;
                     const int s1 = incl - __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xe, 0xf, false);
-                    if (tail) {
+                    if (tail && runs) {
                         lds_u32d_t *hp = lds_at_d(h.y);
                         __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_add(hp + 1, (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (LOG && logrow) logrow[sidx] = (unsigned char)s1;
                     }
                 } else {
-                    __hip_atomic_fetch_add(lds_at_d(h.y + 4u * val), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (runs) __hip_atomic_fetch_add(lds_at_d(h.y + 4u * val), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if constexpr (LOG) { // one count per value among the 16 chains of my step slot
+                        const unsigned long long rowmask = 0xffffull << (16u * j);
+#pragma unroll
+                        for (uint32_t c = 0; c < (uint32_t)MAXC; ++c) {
+                            const unsigned long long m = __ballot(runs && val == c) & rowmask;
+                            if (tail && runs && logrow && c < p.log_vals) logrow[(size_t)sidx * p.log_vals + c] = (unsigned char)__popcll(m);
+                        }
+                    }
                 }
             }
         }
@@ -226,11 +249,11 @@ static hipError_t launch_dir4_t(const FastParams &p, uint32_t blocks, uint32_t l
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
         return hipGetLastError();
     };
-    return p.counting ? go(&k_sweep_dir4<MAXC, VLDS, ELDS, true>) : go(&k_sweep_dir4<MAXC, VLDS, ELDS, false>);
+    return !p.counting ? go(&k_sweep_dir4<MAXC, VLDS, ELDS, 0>) : p.log ? go(&k_sweep_dir4<MAXC, VLDS, ELDS, 2>) : go(&k_sweep_dir4<MAXC, VLDS, ELDS, 1>);
 }
 
 hipError_t launch_sweep_dir4(const FastParams &p, int max_card, bool views_in_lds, bool entries_in_lds, uint32_t blocks, uint32_t lds, hipStream_t s) {
-    if (p.log || max_card > 4) return hipErrorInvalidValue;
+    if (max_card > 4) return hipErrorInvalidValue;
     auto pick = [&](auto mc) -> hipError_t {
         constexpr int MC = decltype(mc)::value;
         if (views_in_lds) return entries_in_lds ? launch_dir4_t<MC, true, true>(p, blocks, lds, s) : launch_dir4_t<MC, true, false>(p, blocks, lds, s);

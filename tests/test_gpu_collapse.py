@@ -373,7 +373,25 @@ def _expected_rings(em, n, cw, groups):
     return batches * 2 * n, made, first, second
 
 
+def _ring_model(n, deg, cards, seed):
+    """n variables on a ring, every variable sharing a pairwise factor with its next `deg` neighbours (blanket 2 * deg):
+    large enough blankets push a small model off the LDS-table / memoised paths"""
+    from types import SimpleNamespace
+    rng = np.random.default_rng(seed)
+    card = [int(rng.choice(cards)) for _ in range(n)]
+    scopes, tables = [], []
+    for v in range(n):
+        scopes.append([v]); tables.append(np.exp(rng.uniform(-1, 1, card[v])))
+        for d in range(1, deg + 1):
+            u = (v + d) % n
+            scopes.append([v, u]); tables.append(np.exp(rng.uniform(-1, 1, card[v] * card[u])))
+    return SimpleNamespace(card=card, scopes=scopes, tables=tables, fixed=[-1] * n)
+
+
 @pytest.mark.parametrize("model,cw,chains,flags,path", [
+    ("ring24_deg6", 4, 128, 0, 3),      # 24 x 2^12 threshold words: the 4-lane form with tables from global memory, logged
+    ("ring20_deg10_binary", 4, 128, 0, 8),  # blankets of 20 binary variables: not memoisable -> step-parallel direct kernel, logged
+    ("ring18_deg6_card4", 3, 64, 0, 8),     # cards 2..4, blankets of 12: step-parallel direct kernel, one logged count per value
     ("grid3x3", 6, 192, 0, 3),
     ("grid3x3", 7, 192, g.GR_FLAG_CHAIN_PER_LANE, 2),
     ("grid3x3", 6, 128, g.GR_FLAG_DIRECT, 0),
@@ -385,10 +403,14 @@ def test_advance_chain_stop_rule_and_rings_vs_emulator(res_dir, model, cw, chain
     from tests import exact_chain
     from tests.emulator import Emulator
     from tests.test_gpu_parity import _thresholds_from_device, _gm
-    pm = uai_py.load(res_dir, model) if model.endswith(".uai") else exact_chain.tiny_models()[model]
+    rings = {"ring24_deg6": lambda: _ring_model(24, 6, [2], 1), "ring20_deg10_binary": lambda: _ring_model(20, 10, [2], 2),
+             "ring18_deg6_card4": lambda: _ring_model(18, 6, [2, 3, 4], 3)}
+    pm = uai_py.load(res_dir, model) if model.endswith(".uai") else rings[model]() if model in rings else exact_chain.tiny_models()[model]
     n = len(pm.card)
     s = g.HIPChains(_gm(pm), chains, seed=77, flags=flags)
     assert s.info()["path"] == path
+    if model == "ring24_deg6":
+        assert s.info()["tables_in_lds"] == 0
     free = [v for v in range(n) if pm.fixed[v] < 0]
     em = Emulator(pm.card, pm.fixed, free, _thresholds_from_device(s, pm.card), chains, 77)
     s.BurnIn(13); em.run(13, False)  # quad-unaligned start of the window
