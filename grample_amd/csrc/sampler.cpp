@@ -177,7 +177,7 @@ void gr_sampler::configure() {
         pw4_lds = pw4_hist_off + 4u * (uint32_t)H * 4u;
         // measured on ObjectDetection_13: 1.9x the chain-per-lane form at 32 768 chains (2 wavefronts per SIMD instead of
         // one on half of the SIMDs), still 1.5x at 262 144 (fewer table bytes in flight per wavefront) -- so: whenever it fits
-        pw4 = pw4_lds <= kLdsBudget;
+        pw4 = pw4_lds + 64u <= kLdsBudget; // (+ 64 bytes of draw-log scratch)
     }
     // step-parallel direct form: blankets too large to memoise, at most 4 values per variable, arity <= 4, everything a
     // 16-byte factor entry has to hold fits 16 bits (state rows 80 bytes apart: up to 819 variables; byte strides < 64 KiB)
@@ -589,7 +589,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     hip_check(hipEventRecord(ev0, stream), "hipEventRecord");
     auto generic = [&](uint64_t n_total) {
         uint64_t left = n_total;
-        const bool use_pw4 = pw4 && !cur_log; // (a logged window runs the chain-per-lane kernel, the only one built with the log code)
+        const bool use_pw4 = pw4;
         if (use_pw4 && !d_scan_vars.p) {
             // <= 256 MiB of scan variables per launch (2 bytes per step and 64-chain group), + 2 quads of slack for unaligned ends
             const uint64_t groups = o.n_chains / 64u;
@@ -616,9 +616,9 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 const uint32_t n_quads = (uint32_t)(((step + n - 1) >> 2) - (step >> 2) + 1);
                 p.scan_vars = d_scan_vars.p; p.scan_pitch = pw4_plan_steps / 4u + 2u;
                 hip_check(launch_scan_vars(a, n_quads, p.scan_pitch, d_scan_vars.p, stream), "k_scan_vars launch");
-                p.lds_hist_off = pw4_hist_off;
-                hip_check(launch_sweep_pw4(p, act / 64u, pw4_lds, stream), "k_sweep_pw4 launch");
-                p.lds_hist_off = lds_hist_off;
+                p.lds_hist_off = pw4_hist_off; p.lds_tab_off = pw4_lds; // (behind the histograms: 64 bytes of log scratch)
+                hip_check(launch_sweep_pw4(p, act / 64u, pw4_lds + 64u, stream), "k_sweep_pw4 launch");
+                p.lds_hist_off = lds_hist_off; p.lds_tab_off = lds_tab_off;
             } else
             hip_check(launch_sweep(p, max_card, cpt && !plain, tab_lds && !plain, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, stg,
                                    (act + T - 1) / T, T, lds, stream), "k_sweep launch");
@@ -1409,7 +1409,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         bool binary = true;
         for (uint32_t g = 0; g < (s->o.n_variants > 1 ? s->n_active : 1u) && binary; ++g)
             for (uint32_t v : s->image[g].free_vars) binary = binary && s->card[v] == 2;
-        const uint32_t rows = (s->par || s->dir4) ? 4u : 1u; // the 4-lane forms log one row per wavefront (16 chains)
+        const uint32_t rows = (s->par || s->dir4 || s->pw4) ? 4u : 1u; // the 4-lane forms log one row per wavefront (16 chains)
         const uint32_t log_vals = binary ? 1u : (uint32_t)s->max_card;
         const uint64_t pitch = (L * log_vals + 15u) & ~15ull;
         const bool logging = (binary || !s->fast) && pitch <= 0xfffffff0ull && (uint64_t)n_groups * rows * pitch <= (16ull << 30);

@@ -145,6 +145,9 @@ __device__ __forceinline__ void pw4_cond(float (&w)[NP][4], const int (&C)[NP], 
     else pw4_cond_impl<NP, false>(w, C, du, blk, m1, m2, k1, k2, val);
 }
 
+// LOG: write the draw log of gr_advance_chain (one row per wavefront = 16 chains, one count per value and step) and stop at
+// the group's own stopping time (SweepParams::log / limit); steps run one at a time in that mode.
+template <bool LOG>
 __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -222,6 +225,26 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
             if (counting) atomicAdd(&hist[h.ho + val], 1u);
         }
     };
+    // LOG: how many of the wavefront's 16 chains drew each value -- the chains' lanes park their value in 16 bytes of LDS,
+    // lane c (< 16) counts the bytes equal to c (values are < 16: byte-wise compare without carries) and writes one byte
+    unsigned char *logrow = nullptr, *scr = lds + p.lds_tab_off + wave * 16u;
+    uint32_t lim = 0xffffffffu;
+    if constexpr (LOG) {
+        const uint32_t group = (p.chain0 >> 6) + blockIdx.x;
+        if (p.log) logrow = p.log + ((size_t)group * p.log_rows + wave) * p.log_pitch + p.log_off;
+        if (p.limit) {
+            const uint32_t t = p.limit[group];
+            lim = t > p.win_off ? t - p.win_off : 0u;
+        }
+    }
+    auto log_step = [&](const uint32_t val, const uint32_t sidx) {
+        if (blk == 0u) scr[lane >> 2] = (unsigned char)val;
+        const uint4 b = *reinterpret_cast<const uint4 *>(scr);
+        const uint32_t pat = (lane & 15u) * 0x01010101u;
+        auto differ = [&](uint32_t x) -> uint32_t { return (uint32_t)__builtin_popcount(((x ^ pat) + 0x7f7f7f7fu) & 0x80808080u); };
+        const uint32_t n = 16u - (differ(b.x) + differ(b.y) + differ(b.z) + differ(b.w));
+        if (lane < 16u && lane < p.log_vals && logrow) logrow[(size_t)sidx * p.log_vals + lane] = (unsigned char)n;
+    };
 
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
@@ -233,10 +256,12 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
         while (j < 4) {
             const uint64_t s = (q << 2) + j;
             if (s < step0 || s >= step1) { ++j; continue; }
+            const uint32_t sidx = (uint32_t)(s - step0);
+            if (LOG && sidx >= lim) { ++j; continue; } // the group has finished its AdvanceChain: nothing changes any more
             const StepHdr ha = header(j == 0 ? sc[0] : j == 1 ? sc[1] : j == 2 ? sc[2] : sc[3]); // (no register arrays indexed by j)
             const uint32_t dua = j == 0 ? dr.x : j == 1 ? dr.y : j == 2 ? dr.z : dr.w;
             // the next step runs together with this one when it exists and its variable is neither this one nor a neighbour
-            bool pair = j < 3 && s + 1 < step1;
+            bool pair = !LOG && j < 3 && s + 1 < step1;
             StepHdr hb = ha;
             if (pair) {
                 hb = header(j == 0 ? sc[1] : j == 1 ? sc[2] : sc[3]);
@@ -263,6 +288,8 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
                 uint32_t val[1];
                 pw4_cond<1>(w, C, du, blk, m1, m2, k1, k2, val);
                 commit(ha, val[0]);
+                if constexpr (LOG)
+                    if (counting) log_step(val[0], sidx);
                 j += 1;
             }
         }
@@ -280,10 +307,13 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
 }
 
 hipError_t launch_sweep_pw4(const SweepParams &p, uint32_t blocks, uint32_t lds_bytes, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep_pw4), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sweep_pw4, dim3(blocks), dim3(256), lds_bytes, s, p);
-    return hipGetLastError();
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, s, p);
+        return hipGetLastError();
+    };
+    return (p.log || p.limit) ? go(&k_sweep_pw4<true>) : go(&k_sweep_pw4<false>);
 }
 
 } // namespace gr

@@ -392,6 +392,7 @@ def _ring_model(n, deg, cards, seed):
     ("ring24_deg6", 4, 128, 0, 3),      # 24 x 2^12 threshold words: the 4-lane form with tables from global memory, logged
     ("ring20_deg10_binary", 4, 128, 0, 8),  # blankets of 20 binary variables: not memoisable -> step-parallel direct kernel, logged
     ("ring18_deg6_card4", 3, 64, 0, 8),     # cards 2..4, blankets of 12: step-parallel direct kernel, one logged count per value
+    ("ring12_deg3_card16", 3, 128, 0, 6),   # cards 9..16, pairwise, not memoisable: value-parallel kernel, 16 logged counts per step
     ("grid3x3", 6, 192, 0, 3),
     ("grid3x3", 7, 192, g.GR_FLAG_CHAIN_PER_LANE, 2),
     ("grid3x3", 6, 128, g.GR_FLAG_DIRECT, 0),
@@ -404,7 +405,7 @@ def test_advance_chain_stop_rule_and_rings_vs_emulator(res_dir, model, cw, chain
     from tests.emulator import Emulator
     from tests.test_gpu_parity import _thresholds_from_device, _gm
     rings = {"ring24_deg6": lambda: _ring_model(24, 6, [2], 1), "ring20_deg10_binary": lambda: _ring_model(20, 10, [2], 2),
-             "ring18_deg6_card4": lambda: _ring_model(18, 6, [2, 3, 4], 3)}
+             "ring18_deg6_card4": lambda: _ring_model(18, 6, [2, 3, 4], 3), "ring12_deg3_card16": lambda: _ring_model(12, 3, [9, 11, 16, 16], 4)}
     pm = uai_py.load(res_dir, model) if model.endswith(".uai") else rings[model]() if model in rings else exact_chain.tiny_models()[model]
     n = len(pm.card)
     s = g.HIPChains(_gm(pm), chains, seed=77, flags=flags)
