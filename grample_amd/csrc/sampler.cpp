@@ -605,7 +605,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             p.limit = cur_limit; p.win_off = (uint32_t)(step - cur_log_step0);
             // strict mode runs the direct arithmetic (bit-identical to the memoised tables); with strict_fast the LDS table
             // area holds thresholds, so the views are read from global memory
-            // ... and a logged window (gr_advance_chain) always runs the direct back-end, the only one built with the log code
+            // ... and a logged window (gr_advance_chain) of the generic kernel runs its direct back-end, the one built with the log code
             const bool plain = strict_fast || cur_log != nullptr;
             if (use_pw4) {
                 ScanArgs a{};
