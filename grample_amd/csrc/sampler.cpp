@@ -116,6 +116,8 @@ struct gr_sampler {
     bool dir4_vlds = false, dir4_elds = false; // ... with the view tables / the factor entries staged in LDS
     uint32_t dir_hist_off = 0, dir_view_off = 0, dir_ent_off = 0, dir_lds = 0, dir_slots = 0;
     DevBuf<uint32_t> d_dhdr, d_dent;  // ... its step headers (32 bytes per selectable variable) and factor entries (16 bytes per factor)
+    DevBuf<unsigned char> d_log;        // draw log of gr_advance_chain windows: kept between calls (hundreds of MB: allocating and
+                                        // freeing it every window cost more than the window's kernels), grown when a window needs more
     DevBuf<unsigned short> d_scan_vars; // k_sweep_pw4: the variables of one launch (k_scan_vars), 8 bytes per quad and 64-chain group
     uint32_t pw4_plan_steps = 0;        // steps per k_sweep_pw4 launch (row length of d_scan_vars, multiple of 4)
     bool strict_fast = false;         // GR_FLAG_SCAN_PER_CHAIN on memoised tables (k_sweep_strict, the 4-lane form's LDS layout)
@@ -1414,11 +1416,11 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         const uint64_t pitch = (L * log_vals + 15u) & ~15ull;
         const bool logging = (binary || !s->fast) && pitch <= 0xfffffff0ull && (uint64_t)n_groups * rows * pitch <= (16ull << 30);
         const size_t nH = (size_t)s->o.n_variants * s->H;
-        DevBuf<unsigned char> d_log;
+        DevBuf<unsigned char> &d_log = s->d_log;
         std::vector<uint64_t> c0(nH), c1(nH), c2(nH);
         DevBuf<uint32_t> d_limit;
         if (logging) {
-            d_log.alloc((size_t)n_groups * rows * pitch);
+            if (d_log.n < (size_t)n_groups * rows * pitch) d_log.alloc((size_t)n_groups * rows * pitch);
             hip_check(hipMemsetAsync(d_log.p, 0, (size_t)n_groups * rows * pitch, s->stream), "hipMemset");
             s->cur_log = d_log.p; s->cur_log_pitch = (uint32_t)pitch; s->cur_log_rows = rows; s->cur_log_vals = log_vals; s->cur_log_step0 = s->step;
             // every group stops at its own stopping time, like every reference chain does (chain.go:207-214)

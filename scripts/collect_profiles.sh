@@ -28,4 +28,5 @@ for spec in "ObjectDetection_13.uai 256 50 400" "Segmentation_11.uai 256 20 100"
   echo "== $spec (model chains burn-in-sweeps counted-sweeps; 6 seeds each)" >> $O/seed_noise.txt
   python3 $R/scripts/dev_noise.py $spec 2>&1 | tail -8 >> $O/seed_noise.txt
 done
+python3 $R/scripts/dev_advance_chain.py > $O/advance_chain.txt 2>&1
 echo "all done"
