@@ -545,7 +545,6 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
     const uint32_t n = a.n_vars, H = a.H, g = blockIdx.x, lane = threadIdx.x;
     uint32_t *sn = sm_scan, *o1 = sn + n, *o2 = o1 + H, *rem = o2 + H;
     unsigned short *cv = reinterpret_cast<unsigned short *>(rem + 1);
-    unsigned char *list = reinterpret_cast<unsigned char *>(cv + 256) + lane * 256u;
     unsigned char *cl = reinterpret_cast<unsigned char *>(cv + 256) + 64u * 256u; // [256][log_vals]
     const ScanReplay sr(a, g);
     for (uint32_t v = lane; v < n; v += 64u) sn[v] = 0;
@@ -574,18 +573,35 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
             }
         }
         __syncthreads();
-        uint32_t mine = 0; // (1) my steps, newest first
-        for (int idx = 255; idx >= 0; --idx) {
-            const uint32_t v = cv[idx];
-            if (v != 0xffffu && (v & 63u) == lane) list[mine++] = (unsigned char)idx;
-        }
-        uint32_t most = mine;
+        // (1) which of the chunk's 256 steps are mine (variable mod 64 == lane): step (l, j) is owned by lane o = v & 63, so my
+        // mask over the 64 lanes of plane j is the AND over the 6 bits of o of "lanes whose bit b equals my bit b" -- 6 ballots
+        // per plane instead of every lane scanning all 256 entries (that scan was 90 % of this kernel: 11 ms per Grids_13 window)
+        unsigned long long M[4];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) most = max(most, (uint32_t)__shfl_xor((int)most, o));
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t v = cv[lane * 4u + j];
+            unsigned long long m = __ballot(v != 0xffffu);
+#pragma unroll
+            for (uint32_t b = 0; b < 6; ++b) {
+                const unsigned long long bb = __ballot((v >> b) & 1u);
+                m &= ((lane >> b) & 1u) ? bb : ~bb;
+            }
+            M[j] = m;
+        }
+        // (2) walk my steps newest first (step index = 4 * lane + plane): the lanes walk side by side
         uint32_t full = 0;
-        for (uint32_t k = 0; k < most; ++k) { // (2)
-            if (k < mine) {
-                const uint32_t idx = list[k], v = cv[idx], c = sn[v];
+        for (;;) {
+            int best = -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (M[j]) best = max(best, (63 - __clzll((long long)M[j])) * 4 + j);
+            if (!__any(best >= 0)) break;
+            if (best >= 0) {
+                const unsigned long long bit = ~(1ull << (best >> 2));
+                const int j = best & 3;
+                M[0] = j == 0 ? M[0] & bit : M[0]; M[1] = j == 1 ? M[1] & bit : M[1];
+                M[2] = j == 2 ? M[2] & bit : M[2]; M[3] = j == 3 ? M[3] & bit : M[3];
+                const uint32_t idx = (uint32_t)best, v = cv[idx], c = sn[v];
                 if (c < 2u * half) {
                     uint32_t *o = (c < half ? o2 : o1) + a.hoff[v];
                     if (log_vals == 1) { o[1] += cl[idx]; o[0] += 64u - cl[idx]; }
