@@ -179,7 +179,7 @@ void gr_sampler::configure() {
         pw4_lds = pw4_hist_off + 4u * (uint32_t)H * 4u;
         // measured on ObjectDetection_13: 1.9x the chain-per-lane form at 32 768 chains (2 wavefronts per SIMD instead of
         // one on half of the SIMDs), still 1.5x at 262 144 (fewer table bytes in flight per wavefront) -- so: whenever it fits
-        pw4 = pw4_lds + 64u <= kLdsBudget; // (+ 64 bytes of draw-log scratch)
+        pw4 = pw4_lds <= kLdsBudget;
     }
     // step-parallel direct form: blankets too large to memoise, at most 4 values per variable, arity <= 4, everything a
     // 16-byte factor entry has to hold fits 16 bits (state rows 80 bytes apart: up to 819 variables; byte strides < 64 KiB)
@@ -618,9 +618,9 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 const uint32_t n_quads = (uint32_t)(((step + n - 1) >> 2) - (step >> 2) + 1);
                 p.scan_vars = d_scan_vars.p; p.scan_pitch = pw4_plan_steps / 4u + 2u;
                 hip_check(launch_scan_vars(a, n_quads, p.scan_pitch, d_scan_vars.p, stream), "k_scan_vars launch");
-                p.lds_hist_off = pw4_hist_off; p.lds_tab_off = pw4_lds; // (behind the histograms: 64 bytes of log scratch)
-                hip_check(launch_sweep_pw4(p, act / 64u, pw4_lds + 64u, stream), "k_sweep_pw4 launch");
-                p.lds_hist_off = lds_hist_off; p.lds_tab_off = lds_tab_off;
+                p.lds_hist_off = pw4_hist_off;
+                hip_check(launch_sweep_pw4(p, act / 64u, pw4_lds, stream), "k_sweep_pw4 launch");
+                p.lds_hist_off = lds_hist_off;
             } else
             hip_check(launch_sweep(p, max_card, cpt && !plain, tab_lds && !plain, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, stg,
                                    (act + T - 1) / T, T, lds, stream), "k_sweep launch");

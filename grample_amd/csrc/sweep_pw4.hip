@@ -59,6 +59,14 @@ __device__ __forceinline__ double quad_scan(const double q, const double m1, con
 
 typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2v __attribute__((ext_vector_type(2)));
+// The launch's read-only inputs (scan variables, programs) are read through the constant address space: a uniform address is
+// then always a scalar load, also in the LOG instantiation, whose byte stores to the draw log could alias anything as far
+// as the compiler knows (it had turned every program load into a vector load there: twice the VMEM instructions, +70 % scalar
+// and +120 % branch instructions, 1.6x the time).
+#define GR_CONST_AS __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const GR_CONST_AS T *as_const(const void *p) { return (const GR_CONST_AS T *)(uintptr_t)p; }
 
 // One step's wave-uniform inputs (scalar registers)
 struct StepHdr {
@@ -146,7 +154,7 @@ __device__ __forceinline__ void pw4_cond(float (&w)[NP][4], const int (&C)[NP], 
 }
 
 // LOG: write the draw log of gr_advance_chain (one row per wavefront = 16 chains, one count per value and step) and stop at
-// the group's own stopping time (SweepParams::log / limit); steps run one at a time in that mode.
+// the group's own stopping time (SweepParams::log / limit).
 template <bool LOG>
 __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -163,7 +171,7 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
     __syncthreads();
 
     const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
-    const uint2 *plan = reinterpret_cast<const uint2 *>(p.scan_vars) + (size_t)blockIdx.x * p.scan_pitch; // the block's scan stream
+    const GR_CONST_AS u32x2v *plan = as_const<u32x2v>(reinterpret_cast<const uint2 *>(p.scan_vars) + (size_t)blockIdx.x * p.scan_pitch); // the block's scan stream
     const uint64_t step0 = ((uint64_t)p.step0_hi << 32) | p.step0_lo;
     const uint64_t step1 = step0 + p.n_steps;
     const uint32_t *progs = p.vprogs + vd.vprog_base;
@@ -177,9 +185,9 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
     auto header = [&](const uint32_t v) -> StepHdr {
         StepHdr h;
         h.v = v;
-        h.pg = progs + poff[h.v];
-        const uint4 w = *reinterpret_cast<const uint4 *>(h.pg);
-        h.h = w.x; h.ho = w.y; h.f_lo = w.z; h.f_hi = w.w;
+        h.pg = progs + as_const<uint32_t>(poff)[h.v];
+        const u32x4v w = *as_const<u32x4v>(h.pg);
+        h.h = w[0]; h.ho = w[1]; h.f_lo = w[2]; h.f_hi = w[3];
         return h;
     };
     // f32 log sums of my 4 values, factors in Model.Funcs order (gibbs-simple.go:186).  The padding slots of the program read
@@ -196,7 +204,7 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
         // (valid memory; its values are marked absent in pw4_cond)
         const uint32_t col = 4u * blk < rowlen ? 16u * blk : 0u;
         w[0] = w[1] = w[2] = w[3] = 0.f;
-        const u32x16 *ent = reinterpret_cast<const u32x16 *>(h.pg + 4); // 4 entries of {table offset, state row, stride, 0} each
+        const GR_CONST_AS u32x16 *ent = as_const<u32x16>(h.pg + 4); // 4 entries of {table offset, state row, stride, 0} each
         for (uint32_t f0 = 0; f0 < n_slots; f0 += 8) {
             const u32x16 ea = ent[f0 >> 2], eb = ent[(f0 >> 2) + 1u];
             uint32_t ex[8], ey[8], ez[8];
@@ -225,9 +233,10 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
             if (counting) atomicAdd(&hist[h.ho + val], 1u);
         }
     };
-    // LOG: how many of the wavefront's 16 chains drew each value -- the chains' lanes park their value in 16 bytes of LDS,
-    // lane c (< 16) counts the bytes equal to c (values are < 16: byte-wise compare without carries) and writes one byte
-    unsigned char *logrow = nullptr, *scr = lds + p.lds_tab_off + wave * 16u;
+    // LOG: how many of the wavefront's 16 chains drew each value -- 4 ballots (one per bit of the 4-bit value, over the chains'
+    // block-0 lanes); lane c (< 16) ANDs together, bit by bit, the ballot or its complement according to the bits of c, and
+    // the popcount of that mask is the number of chains that drew c.  No LDS round trip.
+    unsigned char *logrow = nullptr;
     uint32_t lim = 0xffffffffu;
     if constexpr (LOG) {
         const uint32_t group = (p.chain0 >> 6) + blockIdx.x;
@@ -238,18 +247,19 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
         }
     }
     auto log_step = [&](const uint32_t val, const uint32_t sidx) {
-        if (blk == 0u) scr[lane >> 2] = (unsigned char)val;
-        const uint4 b = *reinterpret_cast<const uint4 *>(scr);
-        const uint32_t pat = (lane & 15u) * 0x01010101u;
-        auto differ = [&](uint32_t x) -> uint32_t { return (uint32_t)__builtin_popcount(((x ^ pat) + 0x7f7f7f7fu) & 0x80808080u); };
-        const uint32_t n = 16u - (differ(b.x) + differ(b.y) + differ(b.z) + differ(b.w));
-        if (lane < 16u && lane < p.log_vals && logrow) logrow[(size_t)sidx * p.log_vals + lane] = (unsigned char)n;
+        unsigned long long m = 0x1111111111111111ull; // the chains' block-0 lanes
+#pragma unroll
+        for (uint32_t b = 0; b < 4; ++b) {
+            const unsigned long long bb = __ballot((val >> b) & 1u);
+            m &= ((lane >> b) & 1u) ? bb : ~bb;
+        }
+        if (lane < 16u && lane < p.log_vals && logrow) logrow[(size_t)sidx * p.log_vals + lane] = (unsigned char)__popcll(m);
     };
 
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
-        const uint2 sv = plan[q - (step0 >> 2)]; // the quad's four variables, 16 bits each
-        const uint32_t sc[4] = {sv.x & 0xffffu, sv.x >> 16, sv.y & 0xffffu, sv.y >> 16};
+        const u32x2v sv = plan[q - (step0 >> 2)]; // the quad's four variables, 16 bits each
+        const uint32_t sc[4] = {sv[0] & 0xffffu, sv[0] >> 16, sv[1] & 0xffffu, sv[1] >> 16};
         const u32x4 dr = philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
         int j = 0;
 #pragma unroll 1
@@ -261,7 +271,7 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
             const StepHdr ha = header(j == 0 ? sc[0] : j == 1 ? sc[1] : j == 2 ? sc[2] : sc[3]); // (no register arrays indexed by j)
             const uint32_t dua = j == 0 ? dr.x : j == 1 ? dr.y : j == 2 ? dr.z : dr.w;
             // the next step runs together with this one when it exists and its variable is neither this one nor a neighbour
-            bool pair = !LOG && j < 3 && s + 1 < step1;
+            bool pair = j < 3 && s + 1 < step1 && (!LOG || sidx + 1u < lim);
             StepHdr hb = ha;
             if (pair) {
                 hb = header(j == 0 ? sc[1] : j == 1 ? sc[2] : sc[3]);
@@ -279,6 +289,8 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
                 pw4_cond<2>(w, C, du, blk, m1, m2, k1, k2, val);
                 commit(ha, val[0]);
                 commit(hb, val[1]);
+                if constexpr (LOG)
+                    if (counting) { log_step(val[0], sidx); log_step(val[1], sidx + 1u); }
                 j += 2;
             } else {
                 float w[1][4];
