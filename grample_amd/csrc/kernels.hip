@@ -33,18 +33,27 @@ namespace gr {
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
+// Programs, program offsets and the free list are read-only for a launch.  k_sweep reads them through the constant address
+// space: a uniform address is then always a scalar load.  Without it the instantiations that store to global memory inside
+// the step loop (STG: chain state; LOG: the draw log) lose every scalar load -- those stores could alias the programs as far
+// as the compiler knows -- and walk the programs with vector loads instead (84 vs 13 in the STG variant).
+#define GR_CONST_AS __attribute__((address_space(4)))
+typedef const GR_CONST_AS uint32_t *cu32p;
+typedef uint32_t u32x4c __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ cu32p as_const(const uint32_t *p) { return (cu32p)(uintptr_t)p; }
+
 // Summed log potentials of variable `pg` (its direct program) for every
 // candidate value, reading neighbour values through `get(var)`.
 // `tab` = this variant's view-table pool (LDS or global).
-template <int MAXC, class Getter>
-__device__ __forceinline__ void log_weights(const uint32_t *__restrict__ pg, const float *tab, Getter get, float (&w)[MAXC],
+template <int MAXC, class Getter, class PG>
+__device__ __forceinline__ void log_weights(PG pg, const float *tab, Getter get, float (&w)[MAXC],
                                             const uint32_t p0, const uint32_t p1, const uint32_t p2, bool &conflict) {
     const uint32_t h = pg[0];
     const uint32_t rowlen = (h >> 8) & 0xffu;
     const uint32_t nf = h >> 16;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) w[i] = 0.f;
-    const uint32_t *q = pg + 2;
+    PG q = pg + 2;
     for (uint32_t f = 0; f < nf; ++f) { // factors in Model.Funcs order (gibbs-simple.go:186)
         uint32_t o = q[0];
         const uint32_t no = q[1];
@@ -77,14 +86,14 @@ __device__ __forceinline__ void log_weights(const uint32_t *__restrict__ pg, con
 // the view tables do not fit LDS: ObjectDetection_13).  Accumulation stays in Model.Funcs order, so
 // the sums are bit-identical to log_weights().
 template <int MAXC, int GF, bool FULLROW, class Getter>
-__device__ __forceinline__ void log_weights_pw_impl(const uint32_t *__restrict__ pg, const float *tab, Getter get, float (&w)[MAXC],
+__device__ __forceinline__ void log_weights_pw_impl(cu32p pg, const float *tab, Getter get, float (&w)[MAXC],
                                                     const uint32_t p0, const uint32_t p1, const uint32_t p2, bool &conflict) {
     const uint32_t h = pg[0];
     const uint32_t rowlen = (h >> 8) & 0xffu;
     const uint32_t nf = h >> 16;
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) w[i] = 0.f;
-    const uint4 *ent = reinterpret_cast<const uint4 *>(pg + 4);
+    const GR_CONST_AS u32x4c *ent = reinterpret_cast<const GR_CONST_AS u32x4c *>(pg + 4);
     constexpr int NV = MAXC <= 2 ? 1 : MAXC / 4;
     for (uint32_t f0 = 0; f0 < nf; f0 += GF) {
         // Slots past the last factor re-read the last entry (clamped index) instead of being branched around: the GF
@@ -93,7 +102,10 @@ __device__ __forceinline__ void log_weights_pw_impl(const uint32_t *__restrict__
         // cache round trip per factor with a lone wavefront per SIMD.)  Only the accumulation is guarded.
         uint4 e[GF];
 #pragma unroll
-        for (int i = 0; i < GF; ++i) e[i] = ent[min(f0 + (uint32_t)i, nf - 1u)];
+        for (int i = 0; i < GF; ++i) {
+            const u32x4c t = ent[min(f0 + (uint32_t)i, nf - 1u)];
+            e[i] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
         const float *row[GF];
 #pragma unroll
         for (int i = 0; i < GF; ++i) {
@@ -131,7 +143,7 @@ __device__ __forceinline__ void log_weights_pw_impl(const uint32_t *__restrict__
 // FULLROW = the variable's rows use all MAXC values: one uniform test up front instead of a scalar guard per row
 // chunk and factor (those guards were most of the kernel's 313 scalar instructions per ObjectDetection_13 step).
 template <int MAXC, int GF, class Getter>
-__device__ __forceinline__ void log_weights_pw(const uint32_t *__restrict__ pg, const float *tab, Getter get, float (&w)[MAXC],
+__device__ __forceinline__ void log_weights_pw(cu32p pg, const float *tab, Getter get, float (&w)[MAXC],
                                                const uint32_t p0, const uint32_t p1, const uint32_t p2, bool &conflict) {
     if (MAXC > 2 && ((pg[0] >> 8) & 0xffu) == (uint32_t)MAXC) log_weights_pw_impl<MAXC, GF, true>(pg, tab, get, w, p0, p1, p2, conflict);
     else log_weights_pw_impl<MAXC, GF, false>(pg, tab, get, w, p0, p1, p2, conflict);
@@ -206,7 +218,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     };
 
     // new value of variable v (program pg) given the current state and the draw u
-    auto sample = [&](const uint32_t *pg, const uint32_t u, const uint32_t p0, const uint32_t p1, const uint32_t p2,
+    auto sample = [&](cu32p pg, const uint32_t u, const uint32_t p0, const uint32_t p1, const uint32_t p2,
                       bool &conflict) -> uint32_t {
         const int C = (int)(pg[0] & 0xffu);
         if constexpr (CPT) {
@@ -242,7 +254,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
             const uint32_t t = p.limit[chain >> 6];
             lim = t > p.win_off ? t - p.win_off : 0u;
         }
-    auto commit = [&](const uint32_t v, const uint32_t *pg, const uint32_t val, const uint32_t sidx) {
+    auto commit = [&](const uint32_t v, cu32p pg, const uint32_t val, const uint32_t sidx) {
         if (LOG && sidx >= lim) return; // the group has finished its AdvanceChain: state, counts and log stay as they are
         if constexpr (STG) { if (active) gst[(size_t)v * p.pitch] = (unsigned char)val; }
         else st[v * T] = (unsigned char)val;
@@ -279,16 +291,16 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
         const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w};
         const uint32_t du[4] = {dr.x, dr.y, dr.z, dr.w};
         uint32_t v[4];
-        const uint32_t *pg[4];
+        cu32p pg[4];
         bool valid[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint64_t s = (q << 2) + j;
             valid[j] = (s >= step0) && (s < step1);
             // VarSample: uniform over the selectable variables
-            if constexpr (PC) v[j] = freev[mul_hi_u32(su[j], vd.n_free)];
-            else v[j] = freev[uni(mul_hi_u32(uni(su[j]), vd.n_free))];
-            pg[j] = progs + poff[v[j]];
+            if constexpr (PC) v[j] = as_const(freev)[mul_hi_u32(su[j], vd.n_free)];
+            else v[j] = as_const(freev)[uni(mul_hi_u32(uni(su[j]), vd.n_free))];
+            pg[j] = as_const(progs) + as_const(poff)[v[j]];
         }
         // Phase A: conditionals of all 4 steps from the current state.  Step j's
         // result is exact unless an earlier step of the quad updates one of its

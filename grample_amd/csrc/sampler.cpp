@@ -382,7 +382,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                 }
                 // direct path, LDS-resident state, but the footprint keeps most wavefronts waiting for a CU (Alchemy_11 at
                 // 131 072 chains: 108 KB per 128-lane block = 512 resident wavefronts for 2 048): leave the state in global
-                // memory instead (2.3e10 -> 3.9e10 updates/s there; slower whenever the LDS form can keep the chip full)
+                // memory instead (2.3e10 -> 5.5e10 updates/s there; slower whenever the LDS form can keep the chip full)
                 if (!fast && !use_cpt && !try_strict_fast && !(o.flags & GR_FLAG_SCAN_PER_CHAIN) && !o.block_threads &&
                     (uint64_t)(o.n_chains / 64u) > 2ull * (kLdsBudget / lds) * (T / 64u) * 256u)
                     state_global();
