@@ -158,6 +158,7 @@ VariantImage CompileVariant(const Model &m, const CompileLimits &lim) {
     // ---- memoised programs: blanket (minus evidence variables, whose value is a constant)
     im.cpt_ok = true;
     uint64_t words = 0;
+    std::vector<uint64_t> tab_words(N, 0); // table size of every selectable variable
     for (int v = 0; v < N; ++v) {
         const Variable &var = m.Vars[v];
         im.cprog_off[v] = (uint32_t)im.cprog.size();
@@ -187,12 +188,27 @@ VariantImage CompileVariant(const Model &m, const CompileLimits &lim) {
             im.cprog.push_back((uint32_t)mult[k]);
         }
         if (selectable) {
-            words += cfgs * (uint64_t)(var.Card > 1 ? var.Card - 1 : 1);
+            tab_words[v] = cfgs * (uint64_t)(var.Card > 1 ? var.Card - 1 : 1);
+            words += tab_words[v];
             im.max_cfg = std::max<uint32_t>(im.max_cfg, (uint32_t)cfgs);
         }
         if (words > lim.max_cpt_words) im.cpt_ok = false;
     }
     im.cpt_words = im.cpt_ok ? (uint32_t)words : 0u;
+    // Pool order: small tables first.  A kernel that can keep only part of the pool in LDS (k_sweep_par4's split mode) stages
+    // a PREFIX of it -- with this order the prefix holds as many variables' tables as possible and the few large ones (the
+    // neighbours of a collapsed variable) stay in global memory.
+    if (im.cpt_ok) {
+        std::vector<int> order;
+        for (int v = 0; v < N; ++v)
+            if (tab_words[v]) order.push_back(v);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return tab_words[a] < tab_words[b]; });
+        uint64_t at = 0;
+        for (int v : order) {
+            im.cprog[im.cprog_off[v] + 2] = (uint32_t)at;
+            at += tab_words[v];
+        }
+    }
     return im;
 }
 

@@ -73,6 +73,7 @@ struct DevBuf {
 };
 
 constexpr uint32_t kLdsBudget = 160 * 1024;   // LDS per CU on gfx950
+constexpr uint32_t kSplitBlocks = 2;          // split threshold pool (k_sweep_par4<.., TABG 2>): resident blocks per CU the LDS part must leave room for
 constexpr uint32_t kMaxStepsPerLaunch = 1u << 20; // keeps the u32 wave histograms far from overflow
 constexpr uint64_t kMaxCptWordsTotal = 4ull << 20; // memoised threshold pools of all chain groups together: 16 MB (L2 / MALL resident)
 
@@ -109,6 +110,7 @@ struct gr_sampler {
     bool par_lean = false;            // ... with the lean LDS layout: records always from global memory (large models)
     uint32_t par_stride = 80;         // ... bytes between the LDS state rows of consecutive variables
     bool par_tabg = false;            // ... and the threshold tables too (pools that do not fit LDS)
+    uint32_t par_tab_words = 0;       // ... except the first par_tab_words words of every group's pool (split pool; 0 = all global)
     bool stg = false;                 // chain state stays in global memory (k_sweep<.., STG>): models whose state does not fit LDS
     bool pw4 = false;                 // value-parallel form of the direct path (k_sweep_pw4): pairwise, 8 < Card <= 16
     uint32_t pw4_hist_off = 0, pw4_lds = 0;
@@ -344,7 +346,21 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                     par_stride = (slots > 6 && (uint64_t)n_vars * kParStateStride >= 65536u && !try_strict_fast) ? 64u : kParStateStride;
                     uint32_t b2 = ((uint32_t)n_vars * par_stride + 15u) & ~15u;
                     par_hist_off = b2; b2 += ((uint32_t)H * 4u + 15u) & ~15u;
-                    par_tab_off = b2; b2 += tl ? cpt_max * 4u : 0u; // (!tl: thresholds from global memory, k_sweep_par4<.., TABG>)
+                    par_tab_off = b2; // (!tl: thresholds from global memory, k_sweep_par4<.., TABG>)
+                    // ... all of them, or all but a prefix of the pool (the small tables come first, compiled_model.cpp) that is
+                    // staged in LDS while a CU still holds kSplitBlocks blocks: a collapsed Segmentation_11 group has 14 - 17 K
+                    // words, nearly all of it in tables of at most 256 words; only the collapsed variable's neighbours are larger
+                    par_tab_words = 0;
+                    if (!tl && !try_strict_fast && o.fast_form == 0) {
+                        // (measured there at 65 536 chains, resident blocks per CU -> updates/s: all global 2.47e11, 4 -> 2.48e11,
+                        // 3 -> 2.67e11, 2 -> 3.10e11, 1 = everything in LDS -> 1.93e11)
+                        const uint32_t per_block = (kLdsBudget / kSplitBlocks) & ~15u;
+                        if (per_block > b2) par_tab_words = std::min<uint32_t>((per_block - b2) / 4u & ~3u, (cpt_max + 3u) & ~3u);
+                        // worth it only when most lookups land in LDS: the split costs every step a branch, and the LDS share
+                        // costs occupancy (dv-rel_3: 2 K of 512 K words would fit -- all global)
+                        if (par_tab_words * 2u < cpt_max) par_tab_words = 0;
+                    }
+                    b2 += tl ? cpt_max * 4u : par_tab_words * 4u;
                     par_rec_off = b2; b2 += nfree_max * rec_stride;
                     par_plan_off = b2; b2 += 4u * 1024u;
                     par_scr_off = b2; b2 += 4u * 64u * 16u;
@@ -490,6 +506,8 @@ void gr_sampler::rebuild() {
                     r[0] = v * par_stride;
                     r[1] = par_hist_off + cp[1] * 4u;
                     r[2] = (par_tabg ? 0u : par_tab_off) + cp[2] * 4u;
+                    if (par_tabg && par_tab_words) // split pool: the table is in the staged prefix, or stays in global memory (bit 31)
+                        r[2] = cp[2] + (1u << nn) <= par_tab_words ? par_tab_off + cp[2] * 4u : (1u << 31) | (cp[2] * 4u);
                     r[3] = nn;
                     const bool packed = par_packed;
                     for (uint32_t i = 0; i < (packed ? (rec_stride == 128u ? 16u : 12u) : 6u); ++i) {
@@ -682,6 +700,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.plan_pitch = plan_steps;
         f.rec_stride = rec_stride;
         f.tab_global = par_tabg ? 1u : 0u;
+        f.par_tab_words = par_tabg ? par_tab_words : 0u;
         f.par_stride = par_stride;
         f.par_recmode = par_lean ? 2u : o.fast_form >= 4 && o.fast_form <= 6 ? o.fast_form - 4u : 99u;
         if (!d_err.p) {
@@ -1663,7 +1682,7 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         out->block_threads = s->T; out->n_blocks = s->blocks;
         out->lds_bytes = s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->dir4 ? s->dir_lds : s->lds; // of the kernel that actually runs
         if (s->fast && s->par) { out->block_threads = s->strict_fast ? s->T : 256u; out->n_blocks = s->active_chains() / 64u; }
-        out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : 0u;
+        out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

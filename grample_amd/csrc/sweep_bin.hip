@@ -324,8 +324,9 @@ struct RecL { // a record as per-lane VGPR values
 template <int SLOTS, bool PACKED>
 __device__ __forceinline__ uint32_t comp4(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
-// TABG: the threshold word comes from global memory (tabg + the record's byte offset) instead of LDS
-template <int SLOTS, bool PACKED, bool TABG = false>
+// TABG 1: the threshold word comes from global memory (tabg + the record's byte offset) instead of LDS
+// TABG 2: split pool -- record word 2 with bit 31 set is a byte offset into the global pool, otherwise an absolute LDS address
+template <int SLOTS, bool PACKED, int TABG = 0>
 __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const unsigned char *lds_c, const unsigned char *tabg, const uint32_t u) {
     uint32_t cfg4 = 0;
     auto slot = [&](const int i) {
@@ -350,8 +351,14 @@ __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const
 #pragma unroll
             for (int i = HEAD; i < SLOTS; ++i) slot(i);
         }
-    const uint32_t T = TABG ? *reinterpret_cast<const uint32_t *>(tabg + (r.h.z + cfg4))
-                            : *lds_at(r.h.z + cfg4); // r.h.z: absolute LDS address (staged records)
+    const uint32_t a = r.h.z + cfg4; // r.h.z: absolute LDS address (staged records), or offset into the global pool
+    uint32_t T;
+    if constexpr (TABG == 2) {
+        if ((int)a < 0) T = *reinterpret_cast<const uint32_t *>(tabg + (a & 0x7fffffffu));
+        else T = *lds_at(a);
+    } else {
+        T = TABG ? *reinterpret_cast<const uint32_t *>(tabg + a) : *lds_at(a);
+    }
     return (u >= T) ? 1u : 0u;
 }
 
@@ -383,8 +390,10 @@ __device__ __forceinline__ uint32_t table_l(const RecL<SLOTS, PACKED> &r, const 
 // vector-memory path is otherwise idle.
 // TABG (with RECMODE 2 only): threshold pools too large for LDS (Pedigree without evidence: 36 K words, dv-rel_3: 512 K) are read
 // from global memory -- one dependent L2 access per step instead of an LDS one, hidden by the block's other wavefronts; still
-// an order of magnitude cheaper than evaluating the conditional from the factor tables.
-template <int SLOTS, bool PACKED, int MODE, int RECMODE, bool TABG = false> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
+// an order of magnitude cheaper than evaluating the conditional from the factor tables.  TABG 2: the first p.par_tab_words
+// words of the pool (the small tables: compiled_model.cpp orders the pool by table size) are staged in LDS, the rest is read
+// from global memory; each record says where its table lives.
+template <int SLOTS, bool PACKED, int MODE, int RECMODE, int TABG = 0> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
 __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     constexpr bool COUNT = MODE != 0, LOG = MODE == 2;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -397,10 +406,10 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     const uint32_t variant = (blockIdx.x * 64u) / p.chains_per_variant;
     const VariantDesc vd = p.variants[variant];
     {   // stage tables + records, this block's 64 chains, zero the block histogram
-        const uint32_t n4 = (vd.cpt_len + 3u) >> 2;
+        const uint32_t n4 = ((TABG == 2 ? min(vd.cpt_len, p.par_tab_words) : vd.cpt_len) + 3u) >> 2;
         const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
         uint4 *dst = reinterpret_cast<uint4 *>(lds + p.par_tab_off);
-        if constexpr (!TABG)
+        if constexpr (TABG != 1)
             for (uint32_t i = tid; i < n4; i += 256) dst[i] = src[i];
         const uint4 *rs = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.recs_par) + (size_t)vd.rec_base * p.rec_stride);
         uint4 *rd = reinterpret_cast<uint4 *>(lds + p.par_rec_off);
@@ -725,8 +734,10 @@ static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t ld
     // where the records come from (p.par_recmode: 0..2 forced, else by occupancy): with fewer than 3 wavefronts per SIMD
     // (256 CUs x 4 SIMDs, 4 wavefronts per block) the kernel is latency-bound -> LDS records fetched together; with more it
     // sits on the LDS pipe -> records from global memory, prefetched an iteration ahead
+    if (p.tab_global && p.par_tab_words) // thresholds partly in LDS, partly from global memory: record mode 2
+        return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 2, 2>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 2, 2>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 2, 2>);
     if (p.tab_global) // thresholds from global memory: record mode 2
-        return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 2, true>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 2, true>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 2, true>);
+        return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 2, 1>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 2, 1>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 2, 1>);
     const int rm = p.par_recmode <= 2u ? (int)p.par_recmode : (blocks * 4u < 3u * 1024u ? 1 : 2);
     if (rm == 2) return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 2>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 2>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 2>);
     if (rm == 1) return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 1>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 1>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 1>);

@@ -225,7 +225,8 @@ typedef struct gr_sampler_info {
                                8 = direct conditional, step-parallel (4 lanes per chain: Card <= 4, arity <= 4, blankets too large to memoise);
                                + 16 when the chain state stays in global memory (paths 0 and 1 only) */
     uint32_t max_card;
-    uint32_t tables_in_lds;
+    uint32_t tables_in_lds; /* threshold / view tables: 1 = staged in LDS, 0 = read from global memory, 2 = split (4-lane memoised form:
+                               the small tables in LDS, the large ones from global memory) */
     uint32_t n_launches_last;
     double kernel_ms_last;
     uint64_t step;          /* updates per chain executed so far (burn-in included) */

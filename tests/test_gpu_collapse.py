@@ -332,6 +332,35 @@ def test_many_chains_grouped_chain_per_lane_fast_path(res_dir):
         assert np.array_equal(a.LastSample(c), d.LastSample(c)) and np.array_equal(a.LastSample(c), b.LastSample(c))
 
 
+def test_split_threshold_pool_equals_direct(res_dir):
+    """Segmentation_11 collapsed in 128 groups: 14 - 17 K threshold words per group, too many to sit in LDS next to the state
+    with two blocks per CU.  The 4-lane form stages the small tables (the head of the pool) in LDS and reads the collapsed
+    variable's neighbours' large ones from global memory (info: tables_in_lds = 2); same process as the direct path."""
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, "Segmentation_11.uai"))
+    K, cpv = 128, 256
+
+    def run(flags):
+        s = g.HIPChains(gm, K * cpv, n_variants=K, seed=11, flags=flags)
+        cvs = [s.Collapse(k, -1)[0] for k in range(K)]
+        s.BurnIn(301)
+        s.Advance(512 + 37)
+        return s, cvs
+
+    a, cva = run(0)
+    i = a.info()
+    assert (i["path"], i["tables_in_lds"]) == (3, 2) and i["lds_bytes"] <= 80 * 1024
+    d, cvd = run(g.GR_FLAG_DIRECT)
+    assert d.info()["path"] == 0 and cvd == cva
+    assert np.array_equal(a.counts(), d.counts())
+    assert np.array_equal(a.checkpoint()["states"], d.checkpoint()["states"])
+    # ... and a logged window (gr_advance_chain: draw log, per-group stopping times) on the split form
+    La, Ld = a.AdvanceChain(2), d.AdvanceChain(2)
+    assert La == Ld and a.TotalSampleCount() == d.TotalSampleCount()
+    assert np.array_equal(a.counts(), d.counts())
+    for x, y in zip(a.window_halves()[:2], d.window_halves()[:2]):
+        assert np.array_equal(x, y)
+
+
 # ------------------------------------------- AdvanceChain: stopping rule + exact ChainHistory halves
 def _expected_rings(em, n, cw, groups):
     """Replay chain.go:180-218 on the emulator: every 64-chain group runs batches of 2N until each of its variables was
