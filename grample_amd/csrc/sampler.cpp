@@ -824,7 +824,10 @@ GR_VISIBLE gr_model *gr_model_create(const gr_model_desc *d) {
             m.Vars.push_back(Variable::New(i, d->card[i]));
             if (d->fixed) m.Vars.back().FixedVal = d->fixed[i];
         }
+        if (d->scope_off[0] < 0 || d->tab_off[0] < 0) throw Error(GR_E_INVALID, "negative offset in the model description");
         for (int f = 0; f < d->n_funcs; ++f) {
+            if (d->scope_off[f + 1] <= d->scope_off[f] || d->tab_off[f + 1] < d->tab_off[f])
+                throw Error(GR_E_INVALID, "scope_off / tab_off must be increasing (Clique " + std::to_string(f) + ")");
             std::vector<int> sc(d->scope_var + d->scope_off[f], d->scope_var + d->scope_off[f + 1]);
             for (int v : sc)
                 if (v < 0 || v >= d->n_vars) throw Error(GR_E_INVALID, "Invalid var idx " + std::to_string(v) + " for Clique " + std::to_string(f));
@@ -868,7 +871,9 @@ GR_VISIBLE int gr_model_apply_evidence(gr_model *m, const char *text, size_t len
 
 GR_VISIBLE gr_model *gr_model_clone(const gr_model *m) {
     if (!m) { fail(GR_E_INVALID, "null model"); return nullptr; }
-    return new gr_model{m->m};
+    gr_model *out = nullptr;
+    guarded([&] { out = new gr_model{m->m}; });
+    return out;
 }
 GR_VISIBLE void gr_model_destroy(gr_model *m) { delete m; }
 GR_VISIBLE int gr_model_n_vars(const gr_model *m) { return m ? (int)m->m.Vars.size() : fail(GR_E_INVALID, "null model"); }
@@ -964,6 +969,7 @@ GR_VISIBLE gr_sampler *gr_sampler_create(const gr_model *m, const gr_sampler_opt
         if (!m) throw Error(GR_E_INVALID, "No model supplied");
         if (!opts || opts->struct_size != sizeof(gr_sampler_opts)) throw Error(GR_E_INVALID, "bad gr_sampler_opts (struct_size)");
         if (opts->n_chains < 1) throw Error(GR_E_INVALID, "n_chains must be >= 1");
+        if (opts->n_chains > (1u << 30)) throw Error(GR_E_INVALID, "n_chains must be <= 2^30 per device");
         if (opts->n_variants < 1 || opts->n_chains % opts->n_variants) throw Error(GR_E_INVALID, "n_chains must be a multiple of n_variants");
         if (opts->n_variants > 1 && (opts->n_chains / opts->n_variants) % 64) throw Error(GR_E_INVALID, "chains per variant must be a multiple of 64");
         if (opts->chain_offset % 64) throw Error(GR_E_INVALID, "chain_offset must be a multiple of 64");
@@ -1018,11 +1024,15 @@ GR_VISIBLE void gr_sampler_destroy(gr_sampler *s) {
 
 GR_VISIBLE int gr_blanket_size(gr_sampler *s, uint32_t variant, int32_t v) {
     if (!s || variant >= s->o.n_variants || v < 0 || v >= s->n_vars) return fail(GR_E_INVALID, "bad argument");
-    return (int)VarNeighbors(s->vmodel[variant])[v].size();
+    int n = 0;
+    const int rc = guarded([&] { n = (int)VarNeighbors(s->vmodel[variant])[v].size(); });
+    return rc == GR_OK ? n : rc;
 }
 GR_VISIBLE int gr_function_count(gr_sampler *s, uint32_t variant, int32_t v) {
     if (!s || variant >= s->o.n_variants || v < 0 || v >= s->n_vars) return fail(GR_E_INVALID, "bad argument");
-    return (int)VarFuncs(s->vmodel[variant])[v].size();
+    int n = 0;
+    const int rc = guarded([&] { n = (int)VarFuncs(s->vmodel[variant])[v].size(); });
+    return rc == GR_OK ? n : rc;
 }
 
 constexpr int kNeighborVarMax = 12; // gibbs-collapsed.go:93
@@ -1281,6 +1291,7 @@ GR_VISIBLE int gr_merge_local(gr_sampler *s, double *out_sum, int32_t *out_coll_
 GR_VISIBLE int gr_merge(gr_sampler *const *samplers, int n, double *out_marginal, int32_t *out_collapsed) {
     return guarded([&] {
         if (!samplers || n < 1 || !out_marginal) throw Error(GR_E_INVALID, "Can not merge 0 chains");
+        if (!samplers[0]) throw Error(GR_E_INVALID, "null sampler");
         const int H = samplers[0]->H, N = samplers[0]->n_vars;
         std::vector<double> sum(H), cm(H), tot(H, 0.0), best_m(H, 0.0);
         std::vector<int32_t> cvv(N), best(N, -1);
@@ -1311,7 +1322,7 @@ GR_VISIBLE int gr_merge(gr_sampler *const *samplers, int n, double *out_marginal
 
 GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t *out) {
     return guarded([&] {
-        if (!samplers || n < 1) throw Error(GR_E_INVALID, "no samplers");
+        if (!samplers || n < 1 || !samplers[0]) throw Error(GR_E_INVALID, "no samplers");
         const size_t cnt = (size_t)samplers[0]->o.n_variants * samplers[0]->H;
         std::vector<int> devs(n);
         for (int i = 0; i < n; ++i) {
@@ -1332,14 +1343,21 @@ GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t 
             // out of place, into a scratch buffer per device: every sampler's own counts stay what its chains sampled, so
             // gr_merge / gr_counts / further gr_advance calls after the reduction see unchanged data
             for (int i = 0; i < n; ++i) { samplers[i]->use(); samplers[i]->d_reduced.alloc(cnt); }
-            std::vector<ncclComm_t> comms(n);
-            if (pInitAll(comms.data(), n, devs.data()) != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclCommInitAll failed");
+            struct Comms { // destroyed on every way out, also when a sync below throws
+                std::vector<ncclComm_t> c;
+                ncclResult_t (*destroy)(ncclComm_t);
+                ~Comms() { for (ncclComm_t x : c) if (x) destroy(x); }
+            } comms{std::vector<ncclComm_t>(n, nullptr), pDestroy};
+            if (pInitAll(comms.c.data(), n, devs.data()) != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclCommInitAll failed");
             pGroupStart();
-            for (int i = 0; i < n; ++i)
-                pAllReduce(samplers[i]->d_counts.p, samplers[i]->d_reduced.p, cnt, ncclUint64, ncclSum, comms[i], samplers[i]->stream);
-            const ncclResult_t r = pGroupEnd();
+            ncclResult_t r = ncclSuccess;
+            for (int i = 0; i < n; ++i) {
+                const ncclResult_t ri = pAllReduce(samplers[i]->d_counts.p, samplers[i]->d_reduced.p, cnt, ncclUint64, ncclSum, comms.c[i], samplers[i]->stream);
+                if (ri != ncclSuccess) r = ri;
+            }
+            const ncclResult_t re = pGroupEnd();
+            if (re != ncclSuccess) r = re;
             for (int i = 0; i < n; ++i) { samplers[i]->use(); samplers[i]->sync(); }
-            for (int i = 0; i < n; ++i) pDestroy(comms[i]);
             if (r != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclAllReduce failed");
             if (out) {
                 gr_sampler *s0 = samplers[0];
