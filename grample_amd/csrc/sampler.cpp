@@ -356,9 +356,17 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                         // 3 -> 2.67e11, 2 -> 3.10e11, 1 = everything in LDS -> 1.93e11)
                         const uint32_t per_block = (kLdsBudget / kSplitBlocks) & ~15u;
                         if (per_block > b2) par_tab_words = std::min<uint32_t>((per_block - b2) / 4u & ~3u, (cpt_max + 3u) & ~3u);
-                        // worth it only when most lookups land in LDS: the split costs every step a branch, and the LDS share
-                        // costs occupancy (dv-rel_3: 2 K of 512 K words would fit -- all global)
-                        if (par_tab_words * 2u < cpt_max) par_tab_words = 0;
+                        // worth it only when most lookups land in LDS (variables are selected uniformly: count variables, not
+                        // words): the split costs every step a branch, and the LDS share costs occupancy (dv-rel_3: 4 of its
+                        // 1 000 tables would fit -- all global)
+                        for (const auto &im : image) {
+                            uint32_t in_lds = 0;
+                            for (uint32_t v : im.free_vars) {
+                                const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
+                                if (cp[2] + (1u << ((cp[0] >> 8) & 0xffu)) <= par_tab_words) ++in_lds;
+                            }
+                            if (in_lds * 2u < im.free_vars.size()) { par_tab_words = 0; break; }
+                        }
                     }
                     b2 += tl ? cpt_max * 4u : par_tab_words * 4u;
                     par_rec_off = b2; b2 += nfree_max * rec_stride;

@@ -13,11 +13,11 @@ for name in sorted(f for f in os.listdir(RES) if f.endswith(".uai")):
                 continue
             s = g.HIPChains(m, nch)
             n = m.n_vars
-            sweeps = max(2, 4000 // n)
+            sweeps = max(20, 40000 // n)
             s.BurnIn(n * 2)
             s.Advance(n * sweeps)
             i = s.info()
-            print(f"{name:26s} ev={int(ev)} N={n:5d} path={i['path']} bt={i['block_threads']:4d} lds={i['lds_bytes']:6d} {i['kernel_ms_last']:8.2f} ms {nch * n * sweeps / (i['kernel_ms_last'] * 1e-3):.3e} updates/s", flush=True)
+            print(f"{name:26s} ev={int(ev)} N={n:5d} path={i['path']} bt={i['block_threads']:4d} lds={i['lds_bytes']:6d} tab={i['tables_in_lds']} {i['kernel_ms_last']:8.2f} ms {nch * n * sweeps / (i['kernel_ms_last'] * 1e-3):.3e} updates/s", flush=True)
             s.close()
         except Exception as e:
             print(f"{name:26s} ev={int(ev)} ERROR {e}", flush=True)
