@@ -48,10 +48,40 @@ int guarded(F &&f) {
     }
 }
 
+// Pinned host staging for every transfer of the control path.  A copy between pageable host memory and the device makes
+// the runtime pin the pages on the fly and unpin them afterwards, and the unmap that follows was measured to hold back the
+// NEXT kernel of the stream by 10 - 20 ms (an adaptive run of 126 group activations: 2.4 s of such waits around 0.3 s of
+// work).  So uploads are staged here and stay valid until the stream has drained (gr_sampler::sync resets the arena);
+// downloads land here and are copied out after the wait (gr_sampler::download).
+struct PinnedArena {
+    struct Block { unsigned char *p; size_t cap; };
+    std::vector<Block> blocks;
+    size_t cur = 0, used = 0; // block in use, bytes used in it
+    PinnedArena() = default;
+    PinnedArena(const PinnedArena &) = delete;
+    PinnedArena &operator=(const PinnedArena &) = delete;
+    ~PinnedArena() { for (auto &b : blocks) (void)hipHostFree(b.p); }
+    void *take(size_t bytes) {
+        bytes = (std::max<size_t>(bytes, 1) + 255u) & ~size_t(255);
+        while (cur < blocks.size() && used + bytes > blocks[cur].cap) { ++cur; used = 0; }
+        if (cur == blocks.size()) {
+            Block b{nullptr, std::max<size_t>(bytes, size_t(4) << 20)};
+            hip_check(hipHostMalloc(reinterpret_cast<void **>(&b.p), b.cap, hipHostMallocDefault), "hipHostMalloc");
+            blocks.push_back(b);
+            used = 0;
+        }
+        void *out = blocks[cur].p + used;
+        used += bytes;
+        return out;
+    }
+    void reset() { cur = 0; used = 0; } // only once nothing in flight reads or writes the arena
+};
+
 template <class T>
 struct DevBuf {
     T *p = nullptr;
-    size_t n = 0;
+    size_t n = 0;   // elements in use
+    size_t cap = 0; // elements allocated
     DevBuf() = default;
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
@@ -59,16 +89,24 @@ struct DevBuf {
     void reset() {
         if (p) (void)hipFree(p);
         p = nullptr;
-        n = 0;
+        n = cap = 0;
     }
+    // (contents undefined afterwards.)  An allocation that is large enough is kept: hipFree synchronises the device and
+    // hipMalloc is slow, and rebuild() runs once per activated chain group in an adaptive run.  Safe because every C-ABI
+    // call drains the stream before it returns and all work on a buffer is ordered on that one stream.
     void alloc(size_t count) {
+        if (p && count <= cap) { n = count; return; }
         reset();
-        n = count;
-        hip_check(hipMalloc(reinterpret_cast<void **>(&p), std::max<size_t>(count, 1) * sizeof(T)), "hipMalloc");
+        const size_t want = std::max<size_t>(count + (count < (4u << 20) ? count / 4 : 0), 1); // headroom: the pools of an adaptive run grow group by group
+        hip_check(hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T)), "hipMalloc");
+        n = count; cap = want;
     }
-    void upload(const std::vector<T> &h, hipStream_t s) {
+    void upload(const std::vector<T> &h, hipStream_t s, PinnedArena &stage) {
         alloc(h.size());
-        if (!h.empty()) hip_check(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s), "hipMemcpy H2D");
+        if (h.empty()) return;
+        void *src = stage.take(h.size() * sizeof(T));
+        memcpy(src, h.data(), h.size() * sizeof(T));
+        hip_check(hipMemcpyAsync(p, src, h.size() * sizeof(T), hipMemcpyHostToDevice, s), "hipMemcpy H2D");
     }
 };
 
@@ -152,12 +190,25 @@ struct gr_sampler {
     uint32_t launches_last = 0;
 
     ~gr_sampler() {
+        if (stream) (void)hipStreamSynchronize(stream); // a failed call may have left copies in flight that use the arena
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
     }
     void use() { hip_check(hipSetDevice(o.device), "hipSetDevice"); }
-    void sync() { hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize"); }
+    void sync() {
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        stage.reset(); // nothing in flight any more
+    }
+    // device -> caller memory, through the pinned arena (see PinnedArena); returns after the data has arrived
+    void download(void *dst, const void *dsrc, size_t bytes) {
+        if (!bytes) { sync(); return; }
+        void *tmp = stage.take(bytes);
+        hip_check(hipMemcpyAsync(tmp, dsrc, bytes, hipMemcpyDeviceToHost, stream), "D2H");
+        sync();
+        memcpy(dst, tmp, bytes); // (reset() only rewinds the arena: the bytes are still there)
+    }
+    PinnedArena stage;
 
     void configure();
     void configure_paths();
@@ -456,19 +507,19 @@ void gr_sampler::rebuild() {
         cprog_off.insert(cprog_off.end(), im.cprog_off.begin(), im.cprog_off.end());
         if (cpt) cpt_total += (im.cpt_words + 3u) & ~3u;
     }
-    d_variants.upload(h_variants, stream);
-    d_progs.upload(progs, stream);
-    d_prog_off.upload(prog_off, stream);
-    d_views.upload(views, stream);
-    d_free.upload(freev, stream);
-    d_cprogs.upload(cprogs, stream);
-    d_cprog_off.upload(cprog_off, stream);
+    d_variants.upload(h_variants, stream, stage);
+    d_progs.upload(progs, stream, stage);
+    d_prog_off.upload(prog_off, stream, stage);
+    d_views.upload(views, stream, stage);
+    d_free.upload(freev, stream, stage);
+    d_cprogs.upload(cprogs, stream, stage);
+    d_cprog_off.upload(cprog_off, stream, stage);
     pprogs.resize(pprogs.size() + 4, 0);
-    d_pprogs.upload(pprogs, stream);
-    d_pprog_off.upload(pprog_off, stream);
+    d_pprogs.upload(pprogs, stream, stage);
+    d_pprog_off.upload(pprog_off, stream, stage);
     vprogs.resize(vprogs.size() + 4, 0);
-    d_vprogs.upload(vprogs, stream);
-    d_vprog_off.upload(vprog_off, stream);
+    d_vprogs.upload(vprogs, stream, stage);
+    d_vprog_off.upload(vprog_off, stream, stage);
     d_cpt.alloc(cpt_total + 4);
     hip_check(hipMemsetAsync(d_cpt.p, 0, (cpt_total + 4) * sizeof(uint32_t), stream), "hipMemset");
     if (cpt)
@@ -501,8 +552,8 @@ void gr_sampler::rebuild() {
                 recs.insert(recs.end(), r, r + kRecDwords);
             }
         }
-        d_variants.upload(h_variants, stream); // now with rec_base
-        d_recs.upload(recs, stream);
+        d_variants.upload(h_variants, stream, stage); // now with rec_base
+        d_recs.upload(recs, stream, stage);
         if (par) { // same records for the step-parallel layout: 80-byte state rows, block-level histogram
             std::vector<uint32_t> rp;
             for (uint32_t g = 0; g < o.n_variants; ++g) {
@@ -526,7 +577,7 @@ void gr_sampler::rebuild() {
                     rp.insert(rp.end(), r, r + rec_stride / 4u);
                 }
             }
-            d_recs_par.upload(rp, stream);
+            d_recs_par.upload(rp, stream, stage);
         }
 
         const uint64_t waves = o.n_chains / 64u;
@@ -571,9 +622,9 @@ void gr_sampler::rebuild() {
             h_variants[g].dent_len = (uint32_t)(ent.size() / 4u) - h_variants[g].dent_base;
         }
         ent.resize(ent.size() + 4, 0);
-        d_variants.upload(h_variants, stream); // now with rec_base
-        d_dhdr.upload(hdr, stream);
-        d_dent.upload(ent, stream);
+        d_variants.upload(h_variants, stream, stage); // now with rec_base
+        d_dhdr.upload(hdr, stream, stage);
+        d_dent.upload(ent, stream, stage);
         const uint64_t waves = o.n_chains / 64u;
         uint64_t ps = (256ull << 20) / (waves * 4ull); // <= 256 MiB of plan per launch
         ps = std::min<uint64_t>(ps, kMaxStepsPerLaunch) & ~15ull;
@@ -763,8 +814,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     }
     hip_check(hipEventRecord(ev1, stream), "hipEventRecord");
     uint32_t dev_err = 0;
-    if (d_err.p) hip_check(hipMemcpyAsync(&dev_err, d_err.p, sizeof dev_err, hipMemcpyDeviceToHost, stream), "D2H");
-    sync();
+    if (d_err.p) download(&dev_err, d_err.p, sizeof dev_err);
+    else sync();
     if (dev_err) throw Error(GR_E_STATE, "device kernel refused to run: its LDS layout assumption does not hold (internal error)");
     float ms = 0;
     hip_check(hipEventElapsedTime(&ms, ev0, ev1), "hipEventElapsedTime");
@@ -1010,8 +1061,8 @@ GR_VISIBLE gr_sampler *gr_sampler_create(const gr_model *m, const gr_sampler_opt
         s->image.assign(opts->n_variants, im);
         s->epoch.assign(opts->n_variants, 0);
         s->pitch = (opts->n_chains + 255u) & ~255u;
-        s->d_card.upload(s->card, s->stream);
-        s->d_fixed.upload(s->fixed, s->stream);
+        s->d_card.upload(s->card, s->stream, s->stage);
+        s->d_fixed.upload(s->fixed, s->stream, s->stage);
         s->d_state.alloc((size_t)s->n_vars * s->pitch);
         hip_check(hipMemsetAsync(s->d_state.p, 0, (size_t)s->n_vars * s->pitch, s->stream), "hipMemset");
         s->d_counts.alloc((size_t)opts->n_variants * s->H);
@@ -1119,10 +1170,10 @@ GR_VISIBLE int gr_collapse(gr_sampler *s, uint32_t variant, int32_t var_idx, int
         DevBuf<uint32_t> d_new_card, d_fac_off, d_fac_stride, d_fac_tab;
         DevBuf<int32_t> d_new_fixed, d_fac_pos;
         DevBuf<double> d_tables, d_out, d_part;
-        d_new_card.upload(new_card, s->stream); d_new_fixed.upload(new_fixed, s->stream);
-        d_fac_off.upload(fac_off, s->stream); d_fac_pos.upload(fac_pos, s->stream);
-        d_fac_stride.upload(fac_stride, s->stream); d_fac_tab.upload(fac_tab, s->stream);
-        d_tables.upload(tables, s->stream);
+        d_new_card.upload(new_card, s->stream, s->stage); d_new_fixed.upload(new_fixed, s->stream, s->stage);
+        d_fac_off.upload(fac_off, s->stream, s->stage); d_fac_pos.upload(fac_pos, s->stream, s->stage);
+        d_fac_stride.upload(fac_stride, s->stream, s->stage); d_fac_tab.upload(fac_tab, s->stream, s->stage);
+        d_tables.upload(tables, s->stream, s->stage);
         d_out.alloc(n_entries);
         d_part.alloc((size_t)nblk * cv.Card);
         CollapseArgs a{};
@@ -1131,9 +1182,8 @@ GR_VISIBLE int gr_collapse(gr_sampler *s, uint32_t variant, int32_t var_idx, int
         a.fac_stride = d_fac_stride.p; a.fac_tab = d_fac_tab.p; a.tables = d_tables.p; a.out_table = d_out.p; a.out_partial = d_part.p;
         hip_check(launch_collapse(a, nblk, s->stream), "k_collapse");
         std::vector<double> part((size_t)nblk * cv.Card);
-        hip_check(hipMemcpyAsync(post.Table.data(), d_out.p, n_entries * sizeof(double), hipMemcpyDeviceToHost, s->stream), "D2H");
-        hip_check(hipMemcpyAsync(part.data(), d_part.p, part.size() * sizeof(double), hipMemcpyDeviceToHost, s->stream), "D2H");
-        s->sync();
+        s->download(post.Table.data(), d_out.p, n_entries * sizeof(double));
+        s->download(part.data(), d_part.p, part.size() * sizeof(double));
         post.IsLog = true; // the kernel already applied UseLogSpace (gibbs-collapsed.go:269)
         Variable marg = cv;
         for (int k = 0; k < cv.Card; ++k) {
@@ -1197,8 +1247,7 @@ GR_VISIBLE int gr_counts(gr_sampler *s, uint64_t *counts, uint64_t *n_updates) {
         if (!s) throw Error(GR_E_INVALID, "null sampler");
         s->use();
         if (counts) {
-            hip_check(hipMemcpyAsync(counts, s->d_counts.p, (size_t)s->o.n_variants * s->H * sizeof(uint64_t), hipMemcpyDeviceToHost, s->stream), "D2H");
-            s->sync();
+            s->download(counts, s->d_counts.p, (size_t)s->o.n_variants * s->H * sizeof(uint64_t));
         }
         if (n_updates && gr_total_samples(s, n_updates)) throw Error(GR_E_INVALID, g_err);
     });
@@ -1213,7 +1262,10 @@ GR_VISIBLE int gr_counts_upload(gr_sampler *s, const uint64_t *counts) {
     return guarded([&] {
         if (!s || !counts) throw Error(GR_E_INVALID, "null argument");
         s->use();
-        hip_check(hipMemcpyAsync(s->d_counts.p, counts, (size_t)s->o.n_variants * s->H * sizeof(uint64_t), hipMemcpyHostToDevice, s->stream), "H2D");
+        const size_t bytes = (size_t)s->o.n_variants * s->H * sizeof(uint64_t);
+        void *tmp = s->stage.take(bytes);
+        memcpy(tmp, counts, bytes);
+        hip_check(hipMemcpyAsync(s->d_counts.p, tmp, bytes, hipMemcpyHostToDevice, s->stream), "H2D");
         s->sync();
     });
 }
@@ -1248,8 +1300,11 @@ GR_VISIBLE int gr_state_download(gr_sampler *s, uint8_t *states) {
     return guarded([&] {
         if (!s || !states) throw Error(GR_E_INVALID, "null argument");
         s->use();
-        hip_check(hipMemcpy2DAsync(states, s->o.n_chains, s->d_state.p, s->pitch, s->o.n_chains, s->n_vars, hipMemcpyDeviceToHost, s->stream), "D2H state");
+        const size_t bytes = (size_t)s->o.n_chains * s->n_vars;
+        void *tmp = s->stage.take(bytes);
+        hip_check(hipMemcpy2DAsync(tmp, s->o.n_chains, s->d_state.p, s->pitch, s->o.n_chains, s->n_vars, hipMemcpyDeviceToHost, s->stream), "D2H state");
         s->sync();
+        memcpy(states, tmp, bytes);
     });
 }
 GR_VISIBLE int gr_state_upload(gr_sampler *s, const uint8_t *states) {
@@ -1262,7 +1317,10 @@ GR_VISIBLE int gr_state_upload(gr_sampler *s, const uint8_t *states) {
                 if (row[c] >= C || (f >= 0 && row[c] != f)) throw Error(GR_E_INVALID, "state value out of range (or contradicting evidence) for variable " + std::to_string(v));
         }
         s->use();
-        hip_check(hipMemcpy2DAsync(s->d_state.p, s->pitch, states, s->o.n_chains, s->o.n_chains, s->n_vars, hipMemcpyHostToDevice, s->stream), "H2D state");
+        const size_t bytes = (size_t)s->o.n_chains * s->n_vars;
+        void *tmp = s->stage.take(bytes);
+        memcpy(tmp, states, bytes);
+        hip_check(hipMemcpy2DAsync(s->d_state.p, s->pitch, tmp, s->o.n_chains, s->o.n_chains, s->n_vars, hipMemcpyHostToDevice, s->stream), "H2D state");
         s->sync();
     });
 }
@@ -1370,8 +1428,7 @@ GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t 
             if (out) {
                 gr_sampler *s0 = samplers[0];
                 s0->use();
-                hip_check(hipMemcpyAsync(out, s0->d_reduced.p, cnt * sizeof(uint64_t), hipMemcpyDeviceToHost, s0->stream), "D2H");
-                s0->sync();
+                s0->download(out, s0->d_reduced.p, cnt * sizeof(uint64_t));
             }
             return;
         }
@@ -1443,8 +1500,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         d_out.alloc(n_groups);
         hip_check(launch_stop_time(a, cw, batch, max_batches, d_out.p, s->stream), "k_stop_time");
         std::vector<uint32_t> nb(n_groups);
-        hip_check(hipMemcpyAsync(nb.data(), d_out.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
-        s->sync();
+        s->download(nb.data(), d_out.p, n_groups * sizeof(uint32_t));
         uint32_t worst = 0;
         for (uint32_t b : nb) {
             if (b == 0xffffffffu) throw Error(GR_E_UNSUPPORTED, "ConvergenceWindow too large: a chain group would need more than 2^31 updates");
@@ -1465,13 +1521,13 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         std::vector<uint64_t> c0(nH), c1(nH), c2(nH);
         DevBuf<uint32_t> d_limit;
         if (logging) {
-            if (d_log.n < (size_t)n_groups * rows * pitch) d_log.alloc((size_t)n_groups * rows * pitch);
+            d_log.alloc((size_t)n_groups * rows * pitch); // (keeps a large enough allocation of an earlier window)
             hip_check(hipMemsetAsync(d_log.p, 0, (size_t)n_groups * rows * pitch, s->stream), "hipMemset");
             s->cur_log = d_log.p; s->cur_log_pitch = (uint32_t)pitch; s->cur_log_rows = rows; s->cur_log_vals = log_vals; s->cur_log_step0 = s->step;
             // every group stops at its own stopping time, like every reference chain does (chain.go:207-214)
             std::vector<uint32_t> lim(n_groups);
             for (uint32_t g = 0; g < n_groups; ++g) lim[g] = nb[g] * batch;
-            d_limit.upload(lim, s->stream);
+            d_limit.upload(lim, s->stream, s->stage);
             s->cur_limit = d_limit.p;
         }
         struct Off { gr_sampler *s; ~Off() { s->cur_log = nullptr; s->cur_limit = nullptr; s->cur_log_rows = 1; s->cur_log_vals = 1; } } off{s};
@@ -1496,15 +1552,14 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
             DevBuf<uint32_t> d_hist, d_status, d_hoff;
             std::vector<uint32_t> hoff(s->n_vars + 1, 0);
             for (int v = 0; v < s->n_vars; ++v) hoff[v + 1] = hoff[v] + (uint32_t)s->card[v];
-            d_hoff.upload(hoff, s->stream);
+            d_hoff.upload(hoff, s->stream, s->stage);
             a.hoff = d_hoff.p; a.H = (uint32_t)s->H;
             d_hist.alloc((size_t)n_groups * 2u * s->H);
             d_status.alloc(n_groups);
             hip_check(launch_ring_halves(a, (uint32_t)L, half, d_log.p, (uint32_t)pitch, rows, log_vals, d_limit.p, d_hist.p, d_status.p, s->stream), "k_ring_halves");
             std::vector<uint32_t> hist((size_t)n_groups * 2u * s->H), status(n_groups);
-            hip_check(hipMemcpyAsync(hist.data(), d_hist.p, hist.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
-            hip_check(hipMemcpyAsync(status.data(), d_status.p, n_groups * sizeof(uint32_t), hipMemcpyDeviceToHost, s->stream), "D2H");
-            s->sync();
+            s->download(hist.data(), d_hist.p, hist.size() * sizeof(uint32_t));
+            s->download(status.data(), d_status.p, n_groups * sizeof(uint32_t));
             for (uint32_t st : status)
                 if (st) throw Error(GR_E_STATE, "a ChainHistory ring is not full after AdvanceChain (internal error)");
             for (uint32_t g = 0; g < n_groups; ++g) {
@@ -1660,8 +1715,10 @@ GR_VISIBLE int gr_state(gr_sampler *s, uint32_t chain, int32_t *out) {
         if (chain >= s->o.n_chains) throw Error(GR_E_INVALID, "chain out of range");
         s->use();
         std::vector<unsigned char> col(s->n_vars);
-        hip_check(hipMemcpy2DAsync(col.data(), 1, s->d_state.p + chain, s->pitch, 1, s->n_vars, hipMemcpyDeviceToHost, s->stream), "D2H state");
+        void *tmp = s->stage.take(s->n_vars);
+        hip_check(hipMemcpy2DAsync(tmp, 1, s->d_state.p + chain, s->pitch, 1, s->n_vars, hipMemcpyDeviceToHost, s->stream), "D2H state");
         s->sync();
+        memcpy(col.data(), tmp, s->n_vars);
         for (int v = 0; v < s->n_vars; ++v) out[v] = col[v];
     });
 }
@@ -1675,7 +1732,9 @@ GR_VISIBLE int gr_set_state(gr_sampler *s, uint32_t chain, const int32_t *in) {
             if (in[v] < 0 || in[v] >= s->card[v]) throw Error(GR_E_INVALID, "state value out of range");
             col[v] = (unsigned char)in[v];
         }
-        hip_check(hipMemcpy2DAsync(s->d_state.p + chain, s->pitch, col.data(), 1, 1, s->n_vars, hipMemcpyHostToDevice, s->stream), "H2D state");
+        void *tmp = s->stage.take(s->n_vars);
+        memcpy(tmp, col.data(), s->n_vars);
+        hip_check(hipMemcpy2DAsync(s->d_state.p + chain, s->pitch, tmp, 1, 1, s->n_vars, hipMemcpyHostToDevice, s->stream), "H2D state");
         s->sync();
     });
 }
@@ -1693,11 +1752,10 @@ GR_VISIBLE int gr_conditional(gr_sampler *s, uint32_t variant, int32_t v, const 
         if (s->dirty) s->rebuild();
         DevBuf<int32_t> d_st;
         DevBuf<double> d_pr;
-        d_st.upload(std::vector<int32_t>(state, state + s->n_vars), s->stream);
+        d_st.upload(std::vector<int32_t>(state, state + s->n_vars), s->stream, s->stage);
         d_pr.alloc(var.Card);
         hip_check(launch_conditional(s->h_variants[variant], s->d_progs.p, s->d_prog_off.p, s->d_views.p, (uint32_t)v, d_st.p, d_pr.p, s->max_card, s->stream), "k_conditional");
-        hip_check(hipMemcpyAsync(probs_out, d_pr.p, var.Card * sizeof(double), hipMemcpyDeviceToHost, s->stream), "D2H");
-        s->sync();
+        s->download(probs_out, d_pr.p, var.Card * sizeof(double));
     });
 }
 
