@@ -216,7 +216,7 @@ struct gr_sampler {
     void rebuild();
     void init_state(uint32_t variant);
     void run(uint64_t updates, bool counting);
-    void burn_group(uint32_t group, uint32_t updates);
+    void burn_groups(uint32_t first, uint32_t last, uint32_t updates);
 };
 
 // Pick block size, LDS layout and conditional path for the current images.
@@ -826,9 +826,10 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     }
 }
 
-// A few uncounted updates on ONE group (NewChain's burn-in for a chain added by Adapt), through the
-// generic kernel restricted to that group's chains, at the step positions just before the current one.
-void gr_sampler::burn_group(uint32_t group, uint32_t updates) {
+// A few uncounted updates on the groups [first, last) only (NewChain's burn-in for the chains added by Adapt), through
+// the generic kernel restricted to those groups' chains, at the step positions just before the current one.
+void gr_sampler::burn_groups(uint32_t first, uint32_t last, uint32_t updates) {
+    if (last <= first) return;
     use();
     if (dirty) rebuild();
     SweepParams p{};
@@ -839,7 +840,7 @@ void gr_sampler::burn_group(uint32_t group, uint32_t updates) {
     p.vprogs = d_vprogs.p; p.vprog_off = d_vprog_off.p;
     p.state = d_state.p; p.counts = d_counts.p;
     p.n_vars = (uint32_t)n_vars; p.H = (uint32_t)H; p.pitch = pitch; p.chains_per_variant = cpv;
-    p.chain0 = group * cpv; p.n_chains = (group + 1) * cpv;
+    p.chain0 = first * cpv; p.n_chains = last * cpv;
     p.chain_offset_lo = (uint32_t)o.chain_offset; p.chain_offset_hi = (uint32_t)(o.chain_offset >> 32);
     p.seed_lo = (uint32_t)o.seed; p.seed_hi = (uint32_t)(o.seed >> 32);
     const uint64_t s0 = step >= updates ? step - updates : 0;
@@ -847,7 +848,7 @@ void gr_sampler::burn_group(uint32_t group, uint32_t updates) {
     p.n_steps = updates; p.counting = 0; p.sequential = 0;
     p.lds_hist_off = lds_hist_off; p.lds_tab_off = lds_tab_off;
     const uint32_t t = std::min(T, 256u);
-    hip_check(launch_sweep(p, max_card, cpt && !strict_fast, tab_lds && !strict_fast, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, stg, (cpv + t - 1) / t, t, lds, stream),
+    hip_check(launch_sweep(p, max_card, cpt && !strict_fast, tab_lds && !strict_fast, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, stg, ((last - first) * cpv + t - 1) / t, t, lds, stream),
               "k_sweep launch (group burn-in)");
     sync();
 }
@@ -1653,6 +1654,21 @@ GR_VISIBLE int gr_adapt_select(const gr_model *base, const int32_t *merged_colla
     });
 }
 
+// The first half of an activation: the next inactive group becomes a fresh clone of the base model with var_idx collapsed
+// (adaptive.go:133-145) and counts as active; its burn-in (and the rebuild of the device pools) is the caller's.
+static int activate_collapsed(gr_sampler *s, int32_t var_idx, int32_t *out_var) {
+    return guarded([&] {
+        if (!s) throw Error(GR_E_INVALID, "null sampler");
+        if (s->n_active >= s->o.n_variants) throw Error(GR_E_STATE, "every chain group is already active");
+        const uint32_t g = s->n_active;
+        int32_t cv = -1;
+        if (gr_collapse(s, g, var_idx, &cv, nullptr)) throw Error(GR_E_COLLAPSE, g_err);
+        s->n_active = g + 1;
+        s->counted_g[g] = 0;
+        if (out_var) *out_var = cv;
+    });
+}
+
 GR_VISIBLE int gr_adapt(gr_sampler *s, uint32_t new_chain_count, int32_t *out_vars, uint32_t *out_n, double *out_converge) {
     return guarded([&] {
         if (!s || !out_vars || !out_n) throw Error(GR_E_INVALID, "null argument");
@@ -1685,27 +1701,33 @@ GR_VISIBLE int gr_adapt(gr_sampler *s, uint32_t new_chain_count, int32_t *out_va
             if (out_converge) std::copy(conv.begin(), conv.end(), out_converge);
             if (gr_adapt_select(&base, coll.data(), conv.data(), slots, sel.data(), &n_sel)) throw Error(GR_E_INVALID, g_err);
         }
-        for (uint32_t i = 0; i < n_sel; ++i) { // adaptive.go:131-153
+        // adaptive.go:131-153, batched: every new group is collapsed first, then ONE rebuild of the device pools and ONE
+        // burn-in launch over all of them (the groups are independent -- streams are keyed by chain and step --, so the result
+        // is what activating them one by one gives; rebuild() is the expensive part of an activation)
+        struct Finish { // ... also for the groups already added when a later collapse is refused
+            gr_sampler *s; uint32_t first;
+            void run() {
+                const uint32_t f = first;
+                first = s->n_active;
+                if (s->n_active > f) { if (s->dirty) s->rebuild(); s->burn_groups(f, s->n_active, 2); }
+            }
+            ~Finish() { try { run(); } catch (...) {} }
+        } finish{s, s->n_active};
+        for (uint32_t i = 0; i < n_sel; ++i) {
             int32_t cv = -1;
-            if (gr_activate_group(s, sel[i], &cv)) throw Error(GR_E_COLLAPSE, g_err);
+            if (activate_collapsed(s, sel[i], &cv)) throw Error(GR_E_COLLAPSE, g_err);
             out_vars[(*out_n)++] = cv;
         }
+        finish.run();
     });
 }
 
 GR_VISIBLE int gr_activate_group(gr_sampler *s, int32_t var_idx, int32_t *out_var) {
     return guarded([&] {
-        if (!s) throw Error(GR_E_INVALID, "null sampler");
-        if (s->n_active >= s->o.n_variants) throw Error(GR_E_STATE, "every chain group is already active");
-        const uint32_t g = s->n_active;
-        int32_t cv = -1;
-        if (gr_collapse(s, g, var_idx, &cv, nullptr)) throw Error(GR_E_COLLAPSE, g_err);
-        s->n_active = g + 1;
-        s->counted_g[g] = 0;
+        if (activate_collapsed(s, var_idx, out_var)) throw Error(GR_E_COLLAPSE, g_err);
         // NewChain(..., burnIn = 2): two uncounted updates on the new group only, at step positions it has not used
         if (s->dirty) s->rebuild();
-        s->burn_group(g, 2);
-        if (out_var) *out_var = cv;
+        s->burn_groups(s->n_active - 1, s->n_active, 2);
     });
 }
 

@@ -306,6 +306,32 @@ def test_adaptive_flow(res_dir):
     assert es["MeanHellinger"] < 0.35  # sanity: a usable estimate
 
 
+def test_adapt_batches_activations_like_one_by_one(res_dir):
+    """gr_adapt collapses all the groups it adds first and then rebuilds the device pools and burns them in ONCE; the
+    outcome is what activating the same variables one group at a time (gr_activate_group) gives, bit for bit."""
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai"))
+    n, K, cpv = 100, 8, 64
+
+    def start():
+        s = g.HIPChains(gm, K * cpv, n_variants=K, seed=5)
+        s.set_active_groups(2)
+        s.BurnIn(3 * n)
+        s.AdvanceWindow(8 * n)
+        return s
+
+    a = start()
+    added, _ = a.Adapt(4)
+    assert len(added) == 4 and a.active_groups() == 6
+    b = start()
+    assert [b.ActivateGroup(v) for v in added] == added
+    for s in (a, b):
+        s.AdvanceWindow(6 * n + 3)
+    assert a.TotalSampleCount() == b.TotalSampleCount()
+    assert np.array_equal(a.counts(), b.counts())
+    assert np.array_equal(a.checkpoint()["states"], b.checkpoint()["states"])
+    assert a.Adapt(8)[0] == b.Adapt(8)[0]  # the next round ranks the same candidates
+
+
 def test_many_chains_grouped_chain_per_lane_fast_path(res_dir):
     """The chain-per-lane fast kernel (used from 98 304 chains up) with several collapsed groups: bit-identical
     to the direct path, and to the 4-lanes-per-chain form forced on the same problem."""
