@@ -365,6 +365,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
         if (pass == 0 && !use_cpt) continue;
         for (bool tl : {true, false}) { // tables (thresholds or views) staged in LDS, else read from global memory / L2
             bool prefer_global_tables = false;
+            if (tl && use_cpt && o.fast_form == 7 && fast_ok && !try_strict_fast) continue; // form 7: the split-pool kernel is asked for
             for (uint32_t t : cands) {
                 if (o.n_variants > 1 && cpv % t) continue;
                 uint32_t ho, to;
@@ -386,7 +387,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                 const uint32_t form = try_strict_fast ? 2u : o.fast_form; // 0 auto, 1 chain per lane, 2 four lanes per chain
                 par_tabg = false;
                 if (fast_ok && use_cpt && !o.block_threads && !(o.flags & GR_FLAG_CHAIN_PER_LANE) && form != 1 &&
-                    (tl || (!try_strict_fast && (o.fast_form < 4 || o.fast_form == 6))) &&
+                    (tl || (!try_strict_fast && (o.fast_form < 4 || o.fast_form >= 6))) &&
                     (form >= 2 || o.n_chains / 64u <= 1536u || !cpl_fast || (kLdsBudget / lds) * (T / 64u) < 8u)) {
                     // (last clause: a chain-per-lane block whose LDS footprint leaves a CU fewer than 8 wavefronts -- large models,
                     // Promedus_17: 125 KB behind ONE wavefront -- loses to the 4-lane form at any chain count: 6.8e10 vs 1.1e11)
@@ -419,6 +420,8 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                             if (in_lds * 2u < im.free_vars.size()) { par_tab_words = 0; break; }
                         }
                     }
+                    // form 7 (cross-checks): the split kernel whatever the occupancy -- half of the largest pool in LDS
+                    if (!tl && !try_strict_fast && o.fast_form == 7) par_tab_words = std::max<uint32_t>(4u, (cpt_max / 2u) & ~3u);
                     b2 += tl ? cpt_max * 4u : par_tab_words * 4u;
                     par_rec_off = b2; b2 += nfree_max * rec_stride;
                     par_plan_off = b2; b2 += 4u * 1024u;
@@ -431,7 +434,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
                     // does not.  With the records read from global memory (record mode 2) the kernel needs neither that copy nor
                     // the plan ring: the "lean" layout ends after the tables.  (Without it such models ran the chain-per-lane
                     // form with one 64-lane block per CU: 125 KB of LDS behind a single wavefront.)
-                    par_lean = (!tl || b2 > kLdsBudget) && par_rec_off <= kLdsBudget && !try_strict_fast && (o.fast_form < 4 || o.fast_form == 6);
+                    par_lean = (!tl || b2 > kLdsBudget) && par_rec_off <= kLdsBudget && !try_strict_fast && (o.fast_form < 4 || o.fast_form >= 6);
                     // ... and whenever dropping the LDS records lets a CU hold more of the blocks it is going to get (collapsed
                     // Segmentation_11, 128 groups: 100 KB -> 62 KB per block = 2 resident blocks per CU instead of 1)
                     if (!par_lean && b2 <= kLdsBudget && !try_strict_fast && o.fast_form == 0) {

@@ -124,7 +124,8 @@ typedef struct gr_sampler_opts {
     uint32_t fast_form;      /* kernel form: 0 = auto; 1 = chain per lane; 2 = 4 lanes per chain (binary memoised models: one lane per step
                                 of a quad; large-Card pairwise models on the direct path: one lane per block of 4 values);
                                 4, 5, 6 = 4 lanes per chain with the step records read from LDS one by one / from LDS together /
-                                from global memory one iteration ahead (2 picks by occupancy) */
+                                from global memory one iteration ahead (2 picks by occupancy); 7 = as 6 with the threshold pool split
+                                between LDS (its first half) and global memory whatever the occupancy (cross-checks of that kernel) */
 } gr_sampler_opts;
 
 /* NewGibbsSimple for every chain (gibbs-simple.go:25-115): clones the model,

@@ -51,7 +51,8 @@ def model(rng, kind):
 def run(m, chains, seed, off, **kw):
     s = g.HIPChains(m, chains, seed=seed, chain_offset=off, **kw)
     s.BurnIn(29); s.Advance(77); s.Advance(50)
-    out = (s.info()["path"], s.counts().copy(), s.checkpoint()["states"].copy())
+    i = s.info()
+    out = (i["path"] + (32 if i["tables_in_lds"] == 2 else 0), s.counts().copy(), s.checkpoint()["states"].copy())  # 35 = path 3, split pool
     s.close()
     return out
 
@@ -70,7 +71,7 @@ def main():
         ref = run(m, chains, seed, off)
         forms = {"chain_per_lane": dict(fast_form=1), "direct": dict(flags=g.GR_FLAG_DIRECT), "sequential": dict(flags=g.GR_FLAG_SEQUENTIAL),
                  "state_global": dict(flags=g.GR_FLAG_STATE_GLOBAL), "state_global_direct": dict(flags=g.GR_FLAG_STATE_GLOBAL | g.GR_FLAG_DIRECT),
-                 "form2": dict(fast_form=2), "form6": dict(fast_form=6)}
+                 "form2": dict(fast_form=2), "form6": dict(fast_form=6), "form7_split_pool": dict(fast_form=7)}
         paths = [ref[0]]
         for name, kw in forms.items():
             try:

@@ -270,12 +270,12 @@ def test_all_kernel_forms_agree_bit_for_bit(res_dir):
     m = g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_13.uai"))
     runs = {}
     for path, kw in {0: dict(flags=g.GR_FLAG_DIRECT), 1: dict(block_threads=64), 2: dict(fast_form=1), 3: dict(fast_form=2),
-                     34: dict(fast_form=4), 35: dict(fast_form=5), 36: dict(fast_form=6)}.items():
+                     34: dict(fast_form=4), 35: dict(fast_form=5), 36: dict(fast_form=6), 37: dict(fast_form=7)}.items():
         s = g.HIPChains(m, 2048, seed=9, chain_offset=64 * 3, **kw)
         s.BurnIn(333); s.Advance(1001); s.Advance(2 * 4096 + 3)
         runs[path] = (s.info()["path"], s.counts(), np.stack([s.LastSample(c) for c in (0, 63, 64, 1000, 2047)]))
-    assert [runs[k][0] for k in sorted(runs)] in ([0, 1, 2, 3, 3, 3, 3], [0, 2, 2, 3, 3, 3, 3])
-    for k in (1, 2, 3, 34, 35, 36):  # 34..36: the 4-lane form's three record sources
+    assert [runs[k][0] for k in sorted(runs)] in ([0, 1, 2, 3, 3, 3, 3, 3], [0, 2, 2, 3, 3, 3, 3, 3])
+    for k in (1, 2, 3, 34, 35, 36, 37):  # 34..36: the 4-lane form's three record sources; 37: split threshold pool
         assert np.array_equal(runs[0][1], runs[k][1]), k
         assert np.array_equal(runs[0][2], runs[k][2]), k
 
@@ -345,7 +345,7 @@ def _pairwise_big_card_model(rng, n=24):
 def test_cross_form_fuzz():
     """scripts/fuzz_forms.py: 32 random models of four shapes (large-Card pairwise, sparse binary, medium-blanket binary, small
     mixed cards with arity up to 4, evidence, near-zero entries) through every kernel form the library can be steered into --
-    default, chain per lane, direct, sequential, state in global memory, strict memoised / direct: all bit-identical."""
+    default, chain per lane, direct, sequential, state in global memory, split threshold pool, strict memoised / direct: all bit-identical."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -354,7 +354,7 @@ def test_cross_form_fuzz():
     last = out.stdout.strip().splitlines()[-1]
     assert last.startswith("paths exercised:")
     seen = eval(last.split(":", 1)[1])
-    assert {0, 1, 3, 6, 8, 16, 17} <= set(seen), seen
+    assert {0, 1, 3, 6, 8, 16, 17, 35} <= set(seen), seen  # (35 = path 3 with the split threshold pool, fast_form 7)
 
 
 @pytest.mark.parametrize("name", ["CSP_12.uai", "CSP_13.uai", "CSP_11.uai", "Alchemy_11.uai"])
