@@ -113,6 +113,8 @@ struct FastParams {
     uint32_t par_stride;         // k_sweep_par4: bytes between the state rows of consecutive variables (80, or 64 for very large models)
     uint32_t tab_global;         // k_sweep_par4: threshold tables too large for LDS -- read from global memory (record word 2 = byte
                                  // offset inside the group's pool); records from global memory too (record mode 2)
+    uint32_t par_spread;         // k_sweep_par4: 1 = launch the 4 wavefronts of a 64-chain group as 4 blocks of 64 lanes (few groups: spread
+                                 // them over the CUs), 0 = one block of 256 lanes per group
     uint32_t par_tab_words;      // k_sweep_par4 with tab_global: the first par_tab_words words of every group's pool are staged in LDS all
                                  // the same (split pool; record word 2 carries bit 31 for a table that stayed in global memory)
 };

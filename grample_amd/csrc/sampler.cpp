@@ -764,6 +764,9 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.tab_global = par_tabg ? 1u : 0u;
         f.par_tab_words = par_tabg ? par_tab_words : 0u;
         f.par_stride = par_stride;
+        // at most one wavefront per CU in the whole launch: give every wavefront a CU of its own (Grids_11 at 4 096 chains
+        // 6.9e10 -> 7.2e10, Segmentation_11 6.3e10 -> 6.7e10; slower as soon as two wavefronts would have to share a CU's LDS)
+        f.par_spread = act / 64u * 4u <= 256u ? 1u : 0u;
         f.par_recmode = par_lean ? 2u : o.fast_form >= 4 && o.fast_form <= 6 ? o.fast_form - 4u : 99u;
         if (!d_err.p) {
             d_err.alloc(1);

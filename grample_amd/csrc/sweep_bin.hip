@@ -397,32 +397,39 @@ template <int SLOTS, bool PACKED, int MODE, int RECMODE, int TABG = 0> // MODE 0
 __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     constexpr bool COUNT = MODE != 0, LOG = MODE == 2;
     extern __shared__ __align__(16) unsigned char lds[];
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // Block shape: 256 lanes = one 64-chain scan group (4 wavefronts of 16 chains), or -- "spread", when the launch has
+    // fewer wavefronts than the chip has SIMDs -- 64 lanes = one of the group's 4 wavefronts per block, so that the four land
+    // on different CUs (each with its own LDS pipe) instead of on the four SIMDs of one.
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, nthr = blockDim.x;
+    const bool spread = nthr == 64u;
+    const uint32_t group = spread ? blockIdx.x >> 2 : blockIdx.x;    // 64-chain scan group
+    const uint32_t wave = spread ? blockIdx.x & 3u : tid >> 6;        // which 16 chains of the group
+    const uint32_t lwave = tid >> 6;                                  // wavefront inside the block (its LDS plan ring)
     // lane = step slot * 16 + chain: every 16-lane LDS lane group reads ONE record / plan word
     // (broadcast, no bank conflict) and a DPP row reduction sums a step's draws
     const uint32_t j = lane >> 4;                    // step slot inside the quad
     const uint32_t cb = wave * 16u + (lane & 15u);   // chain inside the block
-    const uint32_t chain = blockIdx.x * 64u + cb;
-    const uint32_t variant = (blockIdx.x * 64u) / p.chains_per_variant;
+    const uint32_t chain = group * 64u + cb;
+    const uint32_t variant = (group * 64u) / p.chains_per_variant;
     const VariantDesc vd = p.variants[variant];
     {   // stage tables + records, this block's 64 chains, zero the block histogram
         const uint32_t n4 = ((TABG == 2 ? min(vd.cpt_len, p.par_tab_words) : vd.cpt_len) + 3u) >> 2;
         const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
         uint4 *dst = reinterpret_cast<uint4 *>(lds + p.par_tab_off);
         if constexpr (TABG != 1)
-            for (uint32_t i = tid; i < n4; i += 256) dst[i] = src[i];
+            for (uint32_t i = tid; i < n4; i += nthr) dst[i] = src[i];
         const uint4 *rs = reinterpret_cast<const uint4 *>(reinterpret_cast<const unsigned char *>(p.recs_par) + (size_t)vd.rec_base * p.rec_stride);
         uint4 *rd = reinterpret_cast<uint4 *>(lds + p.par_rec_off);
         const uint32_t per = p.rec_stride / 16u, base = lds_addr_of(lds);
         if constexpr (RECMODE != 2)
-            for (uint32_t i = tid; i < vd.n_free * per; i += 256) {
+            for (uint32_t i = tid; i < vd.n_free * per; i += nthr) {
                 uint4 q = rs[i];
                 if (i % per == 0) { q.y += base; q.z += base; } // histogram and table offsets -> absolute LDS addresses
                 rd[i] = q;
             }
         for (uint32_t v = j; v < p.n_vars; v += 4) lds[v * p.par_stride + cb] = p.state[(size_t)v * p.pitch + chain];
         uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
-        for (uint32_t i = tid; i < p.H; i += 256) h[i] = 0;
+        for (uint32_t i = tid; i < p.H; i += nthr) h[i] = 0;
     }
     __syncthreads();
 
@@ -434,8 +441,8 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     const uint32_t rec_bias = p.par_rec_off - vd.rec_base * p.rec_stride;
 
     // the block's scan plan (all 4 waves walk the same plan), staged per wave through an LDS ring
-    const uint4 *gplan = reinterpret_cast<const uint4 *>(p.plan + (size_t)blockIdx.x * p.plan_pitch);
-    uint4 *ring = reinterpret_cast<uint4 *>(lds + p.par_plan_off + wave * (2u * kPlanChunk * 16u));
+    const uint4 *gplan = reinterpret_cast<const uint4 *>(p.plan + (size_t)group * p.plan_pitch);
+    uint4 *ring = reinterpret_cast<uint4 *>(lds + p.par_plan_off + lwave * (2u * kPlanChunk * 16u));
     const uint32_t *ring_w = reinterpret_cast<const uint32_t *>(ring) + j;
     const uint32_t nchunks = (nq + kPlanChunk - 1) / kPlanChunk;
     auto gload = [&](uint32_t chunk) -> uint4 {
@@ -451,14 +458,14 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
 
     // commit the step slots whose level equals `pass`: write the new values, count them.
     // The 16 chains of a step slot are one DPP row: row_shr 1,2,4,8 leave the number of ones in lane 15.
-    unsigned char *logrow = LOG && p.log ? p.log + (size_t)(blockIdx.x * 4u + wave) * p.log_pitch + p.log_off : nullptr;
+    unsigned char *logrow = LOG && p.log ? p.log + (size_t)(group * 4u + wave) * p.log_pitch + p.log_off : nullptr;
     // A step's value is written at its own level's pass; the counting happens once per step slot after the last pass
     // (histogram adds commute): ones per slot = prefix popcount of the draw mask (V_MBCNT) minus the prefix at the end of
     // the previous DPP row (row_bcast:15) -- valid in lane 15 of every row, the lane that adds to the histogram.
     uint32_t lim = 0xffffffffu; // LOG: the group's own stopping time inside the window (SweepParams::limit)
     if constexpr (LOG)
         if (p.limit) {
-            const uint32_t t = p.limit[blockIdx.x];
+            const uint32_t t = p.limit[group];
             lim = t > p.log_off ? t - p.log_off : 0u;
         }
     auto store = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine, const uint32_t sidx) {
@@ -493,7 +500,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     uint32_t pwn[4] = {0, 0, 0, 0};
     RecL<SLOTS, PACKED> rn[RECMODE == 2 ? 4 : 1];
     // ... and its plan words straight from global memory, two iterations ahead (no LDS ring in this mode)
-    const uint32_t *gplan_w = p.plan + (size_t)blockIdx.x * p.plan_pitch + j;
+    const uint32_t *gplan_w = p.plan + (size_t)group * p.plan_pitch + j;
     uint32_t pwa[4] = {0, 0, 0, 0};
     auto prefetch_plan = [&](const uint32_t gnext) {
 #pragma unroll
@@ -597,7 +604,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         __syncthreads();
         const uint32_t *h = reinterpret_cast<const uint32_t *>(lds + p.par_hist_off);
         unsigned long long *gc = p.counts + (size_t)variant * p.H;
-        for (uint32_t i = tid; i < p.H; i += 256) {
+        for (uint32_t i = tid; i < p.H; i += nthr) {
             const uint32_t c = h[i];
             if (c) atomicAdd(&gc[i], (unsigned long long)c);
         }
@@ -727,7 +734,7 @@ static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t ld
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
+        hipLaunchKernelGGL(kern, dim3(p.par_spread ? blocks * 4u : blocks), dim3(p.par_spread ? 64 : 256), lds, s, p);
         return hipGetLastError();
     };
     // fewer than 3 wavefronts per SIMD (256 CUs x 4 SIMDs, 4 wavefronts per block): latency-bound -> hoisted record reads

@@ -1,4 +1,4 @@
-"""Collapsed Segmentation_11 (128 groups): split threshold pool, resident blocks per CU swept through GRAMPLE_DEV_SPLIT (dev only)."""
+"""Collapsed Segmentation_11 (128 groups): timing of the split threshold pool form (the sweep over resident blocks per CU recorded in DESIGN.md section 3 was made with a development build)."""
 import os, sys, hashlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,4 +15,4 @@ s.BurnIn(n * 10)
 s.Advance(n * 200)
 i = s.info()
 c = np.asarray(s.counts())
-print(f"split={os.environ.get('GRAMPLE_DEV_SPLIT')} chains={nch} path={i['path']} lds={i['lds_bytes']}: {i['kernel_ms_last']:.2f} ms -> {nch * n * 200 / (i['kernel_ms_last'] * 1e-3):.3e} updates/s  counts sha {hashlib.sha1(c.tobytes()).hexdigest()[:12]}", flush=True)
+print(f"chains={nch} path={i['path']} lds={i['lds_bytes']}: {i['kernel_ms_last']:.2f} ms -> {nch * n * 200 / (i['kernel_ms_last'] * 1e-3):.3e} updates/s  counts sha {hashlib.sha1(c.tobytes()).hexdigest()[:12]}", flush=True)
