@@ -561,12 +561,13 @@ void gr_sampler::rebuild() {
             std::vector<uint32_t> rp;
             for (uint32_t g = 0; g < o.n_variants; ++g) {
                 const VariantImage &im = image[g];
+                uint32_t rank = 0;
                 for (uint32_t v : im.free_vars) {
                     const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
                     const uint32_t nn = (cp[0] >> 8) & 0xffu;
                     uint32_t r[32] = {0};
                     r[0] = v * par_stride;
-                    r[1] = par_hist_off + cp[1] * 4u;
+                    r[1] = par_hist_off + 8u * rank++; // block histogram by rank in the free list (flush_rank_hist, sweep_bin.hip)
                     r[2] = (par_tabg ? 0u : par_tab_off) + cp[2] * 4u;
                     if (par_tabg && par_tab_words) // split pool: the table is in the staged prefix, or stays in global memory (bit 31)
                         r[2] = cp[2] + (1u << nn) <= par_tab_words ? par_tab_off + cp[2] * 4u : (1u << 31) | (cp[2] * 4u);

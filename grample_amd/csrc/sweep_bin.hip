@@ -324,11 +324,34 @@ struct RecL { // a record as per-lane VGPR values
 template <int SLOTS, bool PACKED>
 __device__ __forceinline__ uint32_t comp4(const uint4 &v, int i) { return i == 0 ? v.x : i == 1 ? v.y : i == 2 ? v.z : v.w; }
 
+// The block histogram of the kernels that use the 4-lane records (k_sweep_par4, k_sweep_strict) is indexed by the
+// variable's RANK in its group's free list -- words 2 * rank (zeros) and 2 * rank + 1 (ones), always an aligned 8-byte pair,
+// whatever odd-Card evidence variables sit in front of it in the model's own layout -- and mapped to the global counters
+// (the model's layout: histogram offset = word 1 of the variable's memoised program) when the block ends.
+__device__ __forceinline__ void flush_rank_hist(const FastParams &p, const VariantDesc &vd, const uint32_t *h, unsigned long long *gc,
+                                                const uint32_t tid, const uint32_t nthr) {
+    for (uint32_t i = tid; i < vd.n_free; i += nthr) {
+        const uint32_t v = p.free_vars[vd.free_base + i];
+        const uint32_t hoff = p.cprogs[vd.cprog_base + p.cprog_off[vd.cprogoff_base + v] + 1u];
+        const uint32_t c0 = h[2u * i], c1 = h[2u * i + 1u];
+        if (c0) atomicAdd(&gc[hoff], (unsigned long long)c0);
+        if (c1) atomicAdd(&gc[hoff + 1u], (unsigned long long)c1);
+    }
+}
+
+// a * b + c on 24-bit operands in ONE instruction (left alone the compiler pairs the products of a configuration index
+// through V_ADD3: 4 multiplies + 2 adds where 4 multiply-adds do)
+__device__ __forceinline__ uint32_t mad_u24(const uint32_t a, const uint32_t b, const uint32_t c) {
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 // TABG 1: the threshold word comes from global memory (tabg + the record's byte offset) instead of LDS
 // TABG 2: split pool -- record word 2 with bit 31 set is a byte offset into the global pool, otherwise an absolute LDS address
 template <int SLOTS, bool PACKED, int TABG = 0>
 __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const unsigned char *lds_c, const unsigned char *tabg, const uint32_t u) {
-    uint32_t cfg4 = 0;
+    uint32_t cfg4 = PACKED ? 0u : r.h.z; // (unpacked: the table address starts the multiply-add chain)
     auto slot = [&](const int i) {
         uint32_t off, m4;
         if constexpr (PACKED) {
@@ -339,7 +362,8 @@ __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const
             off = comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2));
             m4 = comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2) + 1);
         }
-        cfg4 += __umul24(m4, (uint32_t)lds_c[off]);
+        if constexpr (PACKED) cfg4 += __umul24(m4, (uint32_t)lds_c[off]); // (the compiler folds the half-word select into an SDWA multiply)
+        else cfg4 = mad_u24(m4, (uint32_t)lds_c[off], cfg4);
     };
     // 128-byte records (13..16 slots: a collapsed group, where only the few neighbours of the collapsed variable have more
     // than 8 neighbours): slots 9.. are walked only when one of the wavefront's four steps needs them
@@ -351,7 +375,7 @@ __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const
 #pragma unroll
             for (int i = HEAD; i < SLOTS; ++i) slot(i);
         }
-    const uint32_t a = r.h.z + cfg4; // r.h.z: absolute LDS address (staged records), or offset into the global pool
+    const uint32_t a = PACKED ? r.h.z + cfg4 : cfg4; // r.h.z: absolute LDS address (staged records), or offset into the global pool
     uint32_t T;
     if constexpr (TABG == 2) {
         if ((int)a < 0) T = *reinterpret_cast<const uint32_t *>(tabg + (a & 0x7fffffffu));
@@ -429,7 +453,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             }
         for (uint32_t v = j; v < p.n_vars; v += 4) lds[v * p.par_stride + cb] = p.state[(size_t)v * p.pitch + chain];
         uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
-        for (uint32_t i = tid; i < p.H; i += nthr) h[i] = 0;
+        for (uint32_t i = tid; i < 2u * vd.n_free; i += nthr) h[i] = 0;
     }
     __syncthreads();
 
@@ -468,20 +492,28 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             const uint32_t t = p.limit[group];
             lim = t > p.log_off ? t - p.log_off : 0u;
         }
-    auto store = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const bool mine, const uint32_t sidx) {
-        if (mine && !(LOG && sidx >= lim)) lds[r.h.x + cb] = (unsigned char)val;
+    auto store = [&](const RecL<SLOTS, PACKED> &r, const bool val, const bool mine, const uint32_t sidx) {
+        if (mine && !(LOG && sidx >= lim)) lds[r.h.x + cb] = val ? (unsigned char)1 : (unsigned char)0;
     };
-    auto count = [&](const RecL<SLOTS, PACKED> &r, const uint32_t val, const uint32_t sidx) {
+    // The draws of a step are a wave mask (the compare's own result, in scalar registers; level passes merge masks with scalar
+    // logic).  Ones of my step slot = popcount of the mask's 16 bits of my DPP row: (lo & rm_lo) | (hi & rm_hi) with two
+    // per-lane constants selects them (V_AND, V_AND_OR), V_BCNT counts -- 4 VALU instructions per step with the 16 - ones
+    // below, where prefix counts (V_MBCNT x 2, + own bit, row_bcast:15 difference) took 9.  [Tried: four scalar popcounts packed
+    // into a word of which each lane takes its byte -- 2 VALU but 14 scalar instructions, 6 % slower: with 4 wavefronts per
+    // SIMD every instruction of any kind costs an issue slot.  A DPP subtract (incl - incl of the previous row's lane 15 in
+    // one instruction) does not exist: V_SUB and V_SUBREV with DPP both compute dpp(src0) - src1.]
+    const uint32_t rm_lo = j < 2u ? 0xffffu << (16u * (j & 1u)) : 0u, rm_hi = j >= 2u ? 0xffffu << (16u * (j & 1u)) : 0u;
+    auto count = [&](const RecL<SLOTS, PACKED> &r, const unsigned long long drawn, const uint32_t sidx) {
         if constexpr (COUNT) {
             if (LOG && uni_b(sidx & ~3u) >= lim) return; // the whole quad is past the group's stopping time (limits are even,
                                                          // so a quad is cut between its steps 1 and 2 at most)
-            const unsigned long long drawn = __ballot(val != 0u);
-            const int incl = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(drawn >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)drawn, 0u)) + (int)val;
-            const int s1 = incl - __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xe, 0xf, false);
             if (tail && !(LOG && sidx >= lim)) {
-                lds_u32_t *hp = lds_at(r.h.y); // absolute LDS address (staged records)
-                __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                __hip_atomic_fetch_add(hp + 1, (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                const uint32_t s1 = (uint32_t)__builtin_popcount(((uint32_t)drawn & rm_lo) | ((uint32_t)(drawn >> 32) & rm_hi));
+                uint32_t zeros; // 16 - s1 (as C++ the compiler emits a negate and an add)
+                asm("v_sub_u32_e32 %0, 16, %1" : "=v"(zeros) : "v"(s1));
+                // (zeros, ones) of the variable are an aligned 8-byte pair of the rank-indexed histogram: one LDS atomic
+                __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>((uintptr_t)r.h.y),
+                                       ((unsigned long long)s1 << 32) | zeros, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (LOG && logrow) logrow[sidx] = (unsigned char)s1;
             }
         }
@@ -497,8 +529,12 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         if (threadIdx.x == 0) atomicOr(p.err, 1u);
         return;
     }
-    uint32_t pwn[4] = {0, 0, 0, 0};
-    RecL<SLOTS, PACKED> rn[RECMODE == 2 ? 4 : 1];
+    // Two register sets (A, B) hold the records and plan words of the current and of the next iteration and swap roles every
+    // iteration (the loop below is unrolled by two): with one "next" set copied into one "current" set per iteration the
+    // copy was 42 of the loop's 188 VALU instructions -- on the resource this kernel is bound by.
+    constexpr int NREC = RECMODE == 2 ? 4 : 1;
+    uint32_t pwA[4] = {0, 0, 0, 0}, pwB[4] = {0, 0, 0, 0};
+    RecL<SLOTS, PACKED> rA[NREC], rB[NREC];
     // ... and its plan words straight from global memory, two iterations ahead (no LDS ring in this mode)
     const uint32_t *gplan_w = p.plan + (size_t)group * p.plan_pitch + j;
     uint32_t pwa[4] = {0, 0, 0, 0};
@@ -506,19 +542,20 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) pwa[k] = gplan_w[(size_t)min(gnext + (uint32_t)k, nq - 1u) * 4u]; // never past the plan
     };
-    auto prefetch = [&](const uint32_t gnext) {
+    auto prefetch = [&](RecL<SLOTS, PACKED> (&rx)[NREC], uint32_t (&pwx)[4]) { // the iteration whose plan words are in pwa
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            pwn[k] = pwa[k];
-            const unsigned char *ga = recs_g + (pwn[k] & ~63u);
-            rn[k].h = *reinterpret_cast<const uint4 *>(ga);
+            pwx[k] = pwa[k];
+            const unsigned char *ga = recs_g + (pwx[k] & ~63u);
+            rx[k % NREC].h = *reinterpret_cast<const uint4 *>(ga);
 #pragma unroll
-            for (int i = 0; i < (int)(sizeof(rn[k].s) / sizeof(uint4)); ++i) rn[k].s[i] = *reinterpret_cast<const uint4 *>(ga + 16 + 16 * i);
+            for (int i = 0; i < (int)(sizeof(rx[0].s) / sizeof(uint4)); ++i) rx[k % NREC].s[i] = *reinterpret_cast<const uint4 *>(ga + 16 + 16 * i);
         }
     };
-    if constexpr (RECMODE == 2) { prefetch_plan(0); prefetch(0); prefetch_plan(4); }
+    if constexpr (RECMODE == 2) { prefetch_plan(0); prefetch(rA, pwA); prefetch_plan(4); }
 
-    for (uint32_t g0 = 0; g0 < nq; g0 += 4) {
+    // one iteration = 4 quads = 16 steps of every chain: (rc, pwc) hold its records and plan words, (rx, pwx) receive the next one's
+    auto iteration = [&](const uint32_t g0, RecL<SLOTS, PACKED> (&rc)[NREC], uint32_t (&pwc)[4], RecL<SLOTS, PACKED> (&rx)[NREC], uint32_t (&pwx)[4]) {
         if (RECMODE != 2 && (g0 & (kPlanChunk - 1u)) == kPlanChunk / 2u) {
             const uint32_t nc = g0 / kPlanChunk + 1u;
             if (nc < nchunks) {
@@ -542,18 +579,14 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             U[0] = c[0]; U[1] = c[1]; U[2] = d[0]; U[3] = d[1];
         }
         constexpr bool HOIST = RECMODE != 0;
-        RecL<SLOTS, PACKED> rq[HOIST ? 4 : 1];
+        RecL<SLOTS, PACKED> rq[RECMODE == 1 ? 4 : 1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            if constexpr (RECMODE == 2) {
-                pw[k] = pwn[k];
-                rq[k] = rn[k];
-                // the offsets in the global records are absolute LDS addresses as they are: see the base check above
-            } else {
-                pw[k] = ring_w[((g0 + k) & (2u * kPlanChunk - 1u)) * 4u];
-            }
+            if constexpr (RECMODE == 2) pw[k] = pwc[k];
+            else pw[k] = ring_w[((g0 + k) & (2u * kPlanChunk - 1u)) * 4u];
         }
-        if constexpr (RECMODE == 2) { prefetch(g0 + 4u); prefetch_plan(g0 + 8u); }
+        // (the offsets in the global records are absolute LDS addresses as they are: see the base check above)
+        if constexpr (RECMODE == 2) { prefetch(rx, pwx); prefetch_plan(g0 + 8u); }
         // RECMODE 1: the four records only depend on the plan: fetch them together (one LDS round trip instead of four)
         if constexpr (RECMODE == 1) {
 #pragma unroll
@@ -567,7 +600,9 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             RecL<SLOTS, PACKED> r;
-            if constexpr (HOIST) {
+            if constexpr (RECMODE == 2) {
+                r = rc[k % NREC];
+            } else if constexpr (HOIST) {
                 r = rq[k];
             } else {
                 const unsigned char *ra = lds + rec_bias + (pw[k] & ~63u);
@@ -578,25 +613,32 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             const uint32_t lv = (pw[k] >> 1) & 3u;
             const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
             const uint32_t sidx = (g0 + k) * 4u + j;
-            uint32_t val = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]);
+            const bool val = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
+            unsigned long long drawn = __ballot(val); // the compare's own mask
             store(r, val, lv == 0, sidx);
             if (maxlv >= 1) { // the quad has steps that do not commute: re-gather after the lower levels committed
-                uint32_t v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]);
-                store(r, v2, lv == 1, sidx);
-                val = lv == 1 ? v2 : val;
+                auto again = [&](const uint32_t level) {
+                    const bool v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
+                    store(r, v2, lv == level, sidx);
+                    const unsigned long long mine = __ballot(lv == level);
+                    drawn = (drawn & ~mine) | (__ballot(v2) & mine);
+                };
+                again(1);
                 if (maxlv >= 2) {
-                    v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]);
-                    store(r, v2, lv == 2, sidx);
-                    val = lv == 2 ? v2 : val;
-                    if (maxlv >= 3) {
-                        v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]);
-                        store(r, v2, lv == 3, sidx);
-                        val = lv == 3 ? v2 : val;
-                    }
+                    again(2);
+                    if (maxlv >= 3) again(3);
                 }
             }
-            count(r, val, sidx);
+            count(r, drawn, sidx);
         }
+    };
+    if constexpr (RECMODE == 2) {
+        for (uint32_t g0 = 0; g0 < nq; g0 += 8) {
+            iteration(g0, rA, pwA, rB, pwB);
+            if (g0 + 4u < nq) iteration(g0 + 4u, rB, pwB, rA, pwA);
+        }
+    } else {
+        for (uint32_t g0 = 0; g0 < nq; g0 += 4) iteration(g0, rA, pwA, rB, pwB);
     }
 
     for (uint32_t v = j; v < p.n_vars; v += 4) p.state[(size_t)v * p.pitch + chain] = lds[v * p.par_stride + cb];
@@ -604,10 +646,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         __syncthreads();
         const uint32_t *h = reinterpret_cast<const uint32_t *>(lds + p.par_hist_off);
         unsigned long long *gc = p.counts + (size_t)variant * p.H;
-        for (uint32_t i = tid; i < p.H; i += nthr) {
-            const uint32_t c = h[i];
-            if (c) atomicAdd(&gc[i], (unsigned long long)c);
-        }
+        flush_rank_hist(p, vd, h, gc, tid, nthr);
     }
 }
 
@@ -644,7 +683,7 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
         }
         for (uint32_t v = 0; v < p.n_vars; ++v) st[v * kParStride] = p.state[(size_t)v * p.pitch + chain];
         uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
-        for (uint32_t i = tid; i < p.H; i += T) h[i] = 0;
+        for (uint32_t i = tid; i < 2u * vd.n_free; i += T) h[i] = 0;
     }
     __syncthreads();
     const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
@@ -695,10 +734,7 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
         __syncthreads();
         const uint32_t *h = reinterpret_cast<const uint32_t *>(lds + p.par_hist_off);
         unsigned long long *gc = p.counts + (size_t)variant * p.H;
-        for (uint32_t i = tid; i < p.H; i += T) {
-            const uint32_t c = h[i];
-            if (c) atomicAdd(&gc[i], (unsigned long long)c);
-        }
+        flush_rank_hist(p, vd, h, gc, tid, T);
     }
 }
 
