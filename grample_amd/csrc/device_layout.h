@@ -119,6 +119,15 @@ struct FastParams {
                                  // the same (split pool; record word 2 carries bit 31 for a table that stayed in global memory)
 };
 
+// A scan-plan word (k_scan_plan -> the fast kernels): byte offset of the step's record / header (a multiple of the record
+// stride, 32 at least) in bits 5..29, and
+//   bit 0      the step reads a neighbour written earlier in its quad (k_sweep_bin recomputes it)
+//   bits 1-2   dependency level of the step inside its quad; bits 3-4 the highest level in the quad (the same in its 4 words)
+//   bit 31     level != 0;  bit 30  highest level != 0 -- copies placed so that ONE unsigned compare answers the two questions a
+//              4-lane kernel asks at every step: word < 2^31 <=> "commit in the first pass", word >= 2^30 <=> "the quad needs
+//              more passes" (bit 31 implies bit 30)
+constexpr uint32_t kPlanLevelBit = 1u << 31, kPlanDepsBit = 1u << 30, kPlanOffMask = 0x3fffffffu;
+
 // Arguments of the scan-stream kernels behind gr_advance_chain (k_stop_time, k_ring_halves): one thread per
 // 64-chain scan group replays its variable-selection stream.
 struct ScanArgs {

@@ -77,10 +77,10 @@ __global__ void __launch_bounds__(256) k_scan_plan(const FastParams p) {
         maxlv = max(maxlv, lv);
         // bit 0: reads a neighbour written earlier in the quad (k_sweep_bin recomputes it);
         // bits 1-2: level (k_sweep_par4)
-        out[j] = (vd.rec_base + k[j]) * p.rec_stride | adj_any | (lv << 1);
+        out[j] = (vd.rec_base + k[j]) * p.rec_stride | adj_any | (lv << 1) | (lv ? kPlanLevelBit : 0u);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) out[j] |= maxlv << 3; // bits 3-4: highest level in the quad, in every word
+    for (int j = 0; j < 4; ++j) out[j] |= maxlv << 3 | (maxlv ? kPlanDepsBit : 0u); // bits 3-4: highest level in the quad, in every word
     reinterpret_cast<uint4 *>(p.plan + (size_t)wave * p.plan_pitch)[qi] = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
@@ -92,7 +92,7 @@ struct Rec {
 // that a uniform address always becomes a scalar (s_load) access served by the scalar cache.
 typedef const __attribute__((address_space(4))) uint32_t *const_u32_ptr;
 __device__ __forceinline__ void load_rec(Rec &r, const uint32_t *recs, uint32_t plan_word) {
-    const_u32_ptr rp = (const_u32_ptr)(uintptr_t)(reinterpret_cast<const unsigned char *>(recs) + (plan_word & ~63u));
+    const_u32_ptr rp = (const_u32_ptr)(uintptr_t)(reinterpret_cast<const unsigned char *>(recs) + (plan_word & kPlanOffMask & ~63u));
 #pragma unroll
     for (int i = 0; i < kRecDwords; ++i) r.w[i] = rp[i];
 }
@@ -536,17 +536,21 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     uint32_t pwA[4] = {0, 0, 0, 0}, pwB[4] = {0, 0, 0, 0};
     RecL<SLOTS, PACKED> rA[NREC], rB[NREC];
     // ... and its plan words straight from global memory, two iterations ahead (no LDS ring in this mode)
-    const uint32_t *gplan_w = p.plan + (size_t)group * p.plan_pitch + j;
+    // (buffer loads: the group's plan row is the resource, the quad a scalar offset, the lane's word j * 4 a constant vector
+    // offset -- no address arithmetic on the VALU)
+    const __amdgpu_buffer_rsrc_t plan_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(p.plan + (size_t)group * p.plan_pitch), 0, 0x7fffffff, 0x00020000);
+    const uint32_t j4 = j * 4u;
     uint32_t pwa[4] = {0, 0, 0, 0};
     auto prefetch_plan = [&](const uint32_t gnext) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) pwa[k] = gplan_w[(size_t)min(gnext + (uint32_t)k, nq - 1u) * 4u]; // never past the plan
+        for (int k = 0; k < 4; ++k) pwa[k] = __builtin_amdgcn_raw_buffer_load_b32(plan_rsrc, j4, min(gnext + (uint32_t)k, nq - 1u) * 16u, 0); // never past the plan
     };
     auto prefetch = [&](RecL<SLOTS, PACKED> (&rx)[NREC], uint32_t (&pwx)[4]) { // the iteration whose plan words are in pwa
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             pwx[k] = pwa[k];
-            const unsigned char *ga = recs_g + (pwx[k] & ~63u);
+            const unsigned char *ga = recs_g + (pwx[k] & (kPlanOffMask & ~63u));
             rx[k % NREC].h = *reinterpret_cast<const uint4 *>(ga);
 #pragma unroll
             for (int i = 0; i < (int)(sizeof(rx[0].s) / sizeof(uint4)); ++i) rx[k % NREC].s[i] = *reinterpret_cast<const uint4 *>(ga + 16 + 16 * i);
@@ -591,7 +595,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         if constexpr (RECMODE == 1) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const unsigned char *ra = lds + rec_bias + (pw[k] & ~63u);
+                const unsigned char *ra = lds + rec_bias + (pw[k] & (kPlanOffMask & ~63u));
                 rq[k].h = *reinterpret_cast<const uint4 *>(ra);
 #pragma unroll
                 for (int i = 0; i < (int)(sizeof(rq[k].s) / sizeof(uint4)); ++i) rq[k].s[i] = *reinterpret_cast<const uint4 *>(ra + 16 + 16 * i);
@@ -605,18 +609,18 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             } else if constexpr (HOIST) {
                 r = rq[k];
             } else {
-                const unsigned char *ra = lds + rec_bias + (pw[k] & ~63u);
+                const unsigned char *ra = lds + rec_bias + (pw[k] & (kPlanOffMask & ~63u));
                 r.h = *reinterpret_cast<const uint4 *>(ra);
 #pragma unroll
                 for (int i = 0; i < (int)(sizeof(r.s) / sizeof(uint4)); ++i) r.s[i] = *reinterpret_cast<const uint4 *>(ra + 16 + 16 * i);
             }
-            const uint32_t lv = (pw[k] >> 1) & 3u;
-            const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
             const uint32_t sidx = (g0 + k) * 4u + j;
             const bool val = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
             unsigned long long drawn = __ballot(val); // the compare's own mask
-            store(r, val, lv == 0, sidx);
-            if (maxlv >= 1) { // the quad has steps that do not commute: re-gather after the lower levels committed
+            store(r, val, pw[k] < kPlanLevelBit, sidx); // level 0: commit in the first pass
+            if (__any(pw[k] >= kPlanDepsBit)) { // the quad has steps that do not commute (uniform: the same bit in its 4 words): re-gather after the lower levels committed
+                const uint32_t lv = (pw[k] >> 1) & 3u;
+                const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
                 auto again = [&](const uint32_t level) {
                     const bool v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
                     store(r, v2, lv == level, sidx);

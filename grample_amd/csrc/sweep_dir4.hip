@@ -105,7 +105,7 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             pwn[k] = pwa[k];
-            hn[k] = *reinterpret_cast<const uint4 *>(hdr_g + (pwn[k] & ~31u));
+            hn[k] = *reinterpret_cast<const uint4 *>(hdr_g + (pwn[k] & (kPlanOffMask & ~31u)));
         }
     };
     prefetch_plan(0); prefetch(); prefetch_plan(4);
