@@ -118,6 +118,21 @@ struct PhiloxSteps {
     }
 };
 
+// a * b + c on 24-bit operands in ONE instruction (left alone the compiler pairs the products of a configuration index
+// through V_ADD3: 4 multiplies + 2 adds where 4 multiply-adds do)
+__device__ __forceinline__ uint32_t mad_u24(const uint32_t a, const uint32_t b, const uint32_t c) {
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// ... with the multiplier in a scalar register (chain-per-lane form: the record is wave-uniform)
+__device__ __forceinline__ uint32_t mad_u24_s(const uint32_t a_uniform, const uint32_t b, const uint32_t c) {
+    uint32_t d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "s"(a_uniform), "v"(b), "v"(c));
+    return d;
+}
+
 // gathers the blanket configuration of one step: issues the neighbour-state reads
 template <int SLOTS, bool PACKED>
 __device__ __forceinline__ void read_states(const Rec &r, const unsigned char *lds_tid, uint32_t (&x)[SLOTS]) {
@@ -130,18 +145,21 @@ __device__ __forceinline__ void read_states(const Rec &r, const unsigned char *l
 template <int SLOTS, bool PACKED>
 __device__ __forceinline__ uint32_t table_word(const Rec &r, const uint32_t (&x)[SLOTS], const unsigned char *lds) {
     uint32_t cfg4 = 0;
+    if constexpr (PACKED) {
 #pragma unroll
-    for (int i = 0; i < SLOTS; ++i) {
-        const uint32_t m4 = PACKED ? (r.w[4 + i] >> 16) : r.w[5 + 2 * i];
-        cfg4 += __umul24(m4, x[i]);
+        for (int i = 0; i < SLOTS; ++i) cfg4 += __umul24(r.w[4 + i] >> 16, x[i]);
+    } else { // one multiply-add per neighbour (the compiler's own choice is multiplies paired through V_ADD3: 3 per 2 neighbours)
+        cfg4 = __umul24(r.w[5], x[0]);
+#pragma unroll
+        for (int i = 1; i < SLOTS; ++i) cfg4 = mad_u24_s(r.w[5 + 2 * i], x[i], cfg4);
     }
     return *reinterpret_cast<const uint32_t *>(lds + r.w[2] + cfg4);
 }
 template <int SLOTS, bool PACKED>
-__device__ __forceinline__ uint32_t sample_rec(const Rec &r, const unsigned char *lds_tid, const unsigned char *lds, const uint32_t u) {
+__device__ __forceinline__ bool sample_rec(const Rec &r, const unsigned char *lds_tid, const unsigned char *lds, const uint32_t u) {
     uint32_t x[SLOTS];
     read_states<SLOTS, PACKED>(r, lds_tid, x);
-    return (u >= table_word<SLOTS, PACKED>(r, x, lds)) ? 1u : 0u;
+    return u >= table_word<SLOTS, PACKED>(r, x, lds);
 }
 
 constexpr uint32_t kPlanChunk = 32; // quads per staged plan chunk (lanes 0..31 carry one quad each); the LDS ring holds two chunks per wave
@@ -211,11 +229,11 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
             const uint32_t t = p.limit[wave_local];
             lim = t > p.log_off ? t - p.log_off : 0u;
         }
-    auto commit = [&](const Rec &r, const uint32_t val, const uint32_t sidx) {
+    auto commit = [&](const Rec &r, const bool val, const uint32_t sidx) { // val: the compare's own wave mask, counted as it is
         if (LOG && sidx >= lim) return;
-        st[r.w[0]] = (unsigned char)val;
+        st[r.w[0]] = val ? (unsigned char)1 : (unsigned char)0;
         if constexpr (COUNT) {
-            const uint32_t ones = (uint32_t)__popcll(__ballot(val != 0));
+            const uint32_t ones = (uint32_t)__popcll(__ballot(val));
             if (lane < 2) {
                 uint32_t *hp = reinterpret_cast<uint32_t *>(lds + h_addr + r.w[1]);
                 __hip_atomic_fetch_add(hp, (uint32_t)(h_sign * (int)ones + h_base), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -253,7 +271,7 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
         __builtin_amdgcn_sched_barrier(0);
         ph.rounds<2>(); // rounds 9-10 cover the table reads
         __builtin_amdgcn_sched_barrier(0);
-        uint32_t v0 = ph.c0 >= t0, v1 = ph.c1 >= t1, v2 = ph.c2 >= t2, v3 = ph.c3 >= t3;
+        bool v0 = ph.c0 >= t0, v1 = ph.c1 >= t1, v2 = ph.c2 >= t2, v3 = ph.c3 >= t3;
         // commit in order; a step that reads what an earlier step of the quad wrote is recomputed first
         const uint32_t s0 = qi * 4u;
         if (flags == 0) {
@@ -339,14 +357,6 @@ __device__ __forceinline__ void flush_rank_hist(const FastParams &p, const Varia
     }
 }
 
-// a * b + c on 24-bit operands in ONE instruction (left alone the compiler pairs the products of a configuration index
-// through V_ADD3: 4 multiplies + 2 adds where 4 multiply-adds do)
-__device__ __forceinline__ uint32_t mad_u24(const uint32_t a, const uint32_t b, const uint32_t c) {
-    uint32_t d;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
-}
-
 // TABG 1: the threshold word comes from global memory (tabg + the record's byte offset) instead of LDS
 // TABG 2: split pool -- record word 2 with bit 31 set is a byte offset into the global pool, otherwise an absolute LDS address
 template <int SLOTS, bool PACKED, int TABG = 0>
@@ -368,8 +378,18 @@ __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const
     // 128-byte records (13..16 slots: a collapsed group, where only the few neighbours of the collapsed variable have more
     // than 8 neighbours): slots 9.. are walked only when one of the wavefront's four steps needs them
     constexpr int HEAD = SLOTS > 12 ? 8 : SLOTS;
+    if constexpr (PACKED) {
 #pragma unroll
-    for (int i = 0; i < HEAD; ++i) slot(i);
+        for (int i = 0; i < HEAD; ++i) slot(i);
+    } else {
+        // unpacked (<= 6 neighbours): read the bytes in slot order, consume them last first -- LDS returns in order, so the
+        // first multiply-add waits for ALL the reads once instead of each of them waiting for its own (one S_WAITCNT, not SLOTS)
+        uint32_t x[SLOTS];
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) x[i] = (uint32_t)lds_c[comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2))];
+#pragma unroll
+        for (int i = SLOTS - 1; i >= 0; --i) cfg4 = mad_u24(comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2) + 1), x[i], cfg4);
+    }
     if constexpr (SLOTS > HEAD)
         if (__any(r.h.w > (uint32_t)HEAD)) {
 #pragma unroll
