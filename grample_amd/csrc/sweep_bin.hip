@@ -126,6 +126,13 @@ __device__ __forceinline__ uint32_t mad_u24(const uint32_t a, const uint32_t b, 
     return d;
 }
 
+// (high half of w) * (low half of b) + c: the multiplier of a PACKED slot word (row offset | 4 * multiplier << 16) without
+// extracting it first
+__device__ __forceinline__ uint32_t mad_u16_hi(const uint32_t w, const uint32_t b, const uint32_t c) {
+    uint32_t d;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "v"(b), "v"(c));
+    return d;
+}
 // ... with the multiplier in a scalar register (chain-per-lane form: the record is wave-uniform)
 __device__ __forceinline__ uint32_t mad_u24_s(const uint32_t a_uniform, const uint32_t b, const uint32_t c) {
     uint32_t d;
@@ -361,41 +368,31 @@ __device__ __forceinline__ void flush_rank_hist(const FastParams &p, const Varia
 // TABG 2: split pool -- record word 2 with bit 31 set is a byte offset into the global pool, otherwise an absolute LDS address
 template <int SLOTS, bool PACKED, int TABG = 0>
 __device__ __forceinline__ uint32_t sample_l(const RecL<SLOTS, PACKED> &r, const unsigned char *lds_c, const unsigned char *tabg, const uint32_t u) {
-    uint32_t cfg4 = PACKED ? 0u : r.h.z; // (unpacked: the table address starts the multiply-add chain)
-    auto slot = [&](const int i) {
-        uint32_t off, m4;
-        if constexpr (PACKED) {
-            const uint32_t w = comp4<SLOTS, PACKED>(r.s[i / 4], i % 4);
-            off = w & 0xffffu;
-            m4 = w >> 16;
-        } else {
-            off = comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2));
-            m4 = comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2) + 1);
+    // The configuration index is a multiply-add chain that starts at the table address (record word 2), one instruction per
+    // neighbour: V_MAD_U32_U24 on unpacked records, V_MAD_U32_U16 taking the multiplier from the high half of a packed slot
+    // word.  The state bytes are read in slot order and consumed last first: LDS returns in order, so the first multiply-add
+    // waits for all the reads once instead of each of them waiting for its own.
+    uint32_t a = r.h.z; // absolute LDS address (staged records), or offset into the global pool
+    auto walk = [&](auto lo, auto hi) {
+        constexpr int LO = decltype(lo)::value, HI = decltype(hi)::value;
+        uint32_t x[HI - LO];
+#pragma unroll
+        for (int i = LO; i < HI; ++i) {
+            const uint32_t off = PACKED ? (comp4<SLOTS, PACKED>(r.s[i / 4], i % 4) & 0xffffu) : comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2));
+            x[i - LO] = (uint32_t)lds_c[off];
         }
-        if constexpr (PACKED) cfg4 += __umul24(m4, (uint32_t)lds_c[off]); // (the compiler folds the half-word select into an SDWA multiply)
-        else cfg4 = mad_u24(m4, (uint32_t)lds_c[off], cfg4);
+#pragma unroll
+        for (int i = HI - 1; i >= LO; --i) {
+            if constexpr (PACKED) a = mad_u16_hi(comp4<SLOTS, PACKED>(r.s[i / 4], i % 4), x[i - LO], a);
+            else a = mad_u24(comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2) + 1), x[i - LO], a);
+        }
     };
     // 128-byte records (13..16 slots: a collapsed group, where only the few neighbours of the collapsed variable have more
     // than 8 neighbours): slots 9.. are walked only when one of the wavefront's four steps needs them
     constexpr int HEAD = SLOTS > 12 ? 8 : SLOTS;
-    if constexpr (PACKED) {
-#pragma unroll
-        for (int i = 0; i < HEAD; ++i) slot(i);
-    } else {
-        // unpacked (<= 6 neighbours): read the bytes in slot order, consume them last first -- LDS returns in order, so the
-        // first multiply-add waits for ALL the reads once instead of each of them waiting for its own (one S_WAITCNT, not SLOTS)
-        uint32_t x[SLOTS];
-#pragma unroll
-        for (int i = 0; i < SLOTS; ++i) x[i] = (uint32_t)lds_c[comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2))];
-#pragma unroll
-        for (int i = SLOTS - 1; i >= 0; --i) cfg4 = mad_u24(comp4<SLOTS, PACKED>(r.s[i / 2], 2 * (i % 2) + 1), x[i], cfg4);
-    }
+    walk(std::integral_constant<int, 0>{}, std::integral_constant<int, HEAD>{});
     if constexpr (SLOTS > HEAD)
-        if (__any(r.h.w > (uint32_t)HEAD)) {
-#pragma unroll
-            for (int i = HEAD; i < SLOTS; ++i) slot(i);
-        }
-    const uint32_t a = PACKED ? r.h.z + cfg4 : cfg4; // r.h.z: absolute LDS address (staged records), or offset into the global pool
+        if (__any(r.h.w > (uint32_t)HEAD)) walk(std::integral_constant<int, HEAD>{}, std::integral_constant<int, SLOTS>{});
     uint32_t T;
     if constexpr (TABG == 2) {
         if ((int)a < 0) T = *reinterpret_cast<const uint32_t *>(tabg + (a & 0x7fffffffu));
