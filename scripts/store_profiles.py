@@ -12,7 +12,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G, P = os.path.join(ROOT, "gpurun_out", TAG), os.path.join(ROOT, "profiles")
-KERN = "k_sweep_par4<4, true, 1, 2, false>"
+KERN = "k_sweep_par4<4, true, 1, 2, 0>"
 UPD_PER_LAUNCH = 50000 * 65536  # a bench step (100 000 updates per chain) = 2 launches
 
 
