@@ -191,7 +191,8 @@ def main():
         # fraction of the HBM peak, and the VALU issue rate as a fraction of the chip's issue peak
         limiter = {"kind": "valu_issue", "unit": "G wave-instructions/s", "peak": VALU_PEAK_GINST,
                    "note": "the working set (chain state, threshold tables, records, histograms) is LDS-resident for a whole launch; "
-                           "the sweep sits on the SIMDs' VALU issue port (4 cycles per wave instruction), see DESIGN.md section 3"}
+                           "the most loaded resource is the SIMDs' VALU issue port (4 cycles per wave instruction; busy 82 % of the wave "
+                           "cycles inside the sweep by the SQ counters), see DESIGN.md sections 3 and 6"}
         if valu_per_update:
             a = valu_per_update / 64.0 * per_launch_updates / per_launch_s / 1e9
             limiter.update({"achieved": a, "frac": a / VALU_PEAK_GINST, "valu_inst_per_64_updates": valu_per_update})
