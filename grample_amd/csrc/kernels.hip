@@ -555,10 +555,13 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
                                                      uint32_t *status) {
     extern __shared__ uint32_t sm_scan[];
     const uint32_t n = a.n_vars, H = a.H, g = blockIdx.x, lane = threadIdx.x;
-    uint32_t *sn = sm_scan, *o1 = sn + n, *o2 = o1 + H, *rem = o2 + H;
+    uint32_t *sn = sm_scan, *o1 = sn + n, *o2 = o1 + H, *hf = o2 + H, *rem = hf + n + 1u;
     unsigned short *cv = reinterpret_cast<unsigned short *>(rem + 1);
-    unsigned char *cl = reinterpret_cast<unsigned char *>(cv + 256) + 64u * 256u; // [256][log_vals]
+    unsigned char *cl = reinterpret_cast<unsigned char *>(cv + 256); // [256][log_vals]
     const ScanReplay sr(a, g);
+    // (histogram offsets in LDS: the walk below looks one up per visited step, right between two LDS accesses -- from global
+    // memory that dependent round trip was most of this kernel's time)
+    for (uint32_t v = lane; v <= n; v += 64u) hf[v] = a.hoff[v];
     for (uint32_t v = lane; v < n; v += 64u) sn[v] = 0;
     for (uint32_t i = lane; i < H; i += 64u) { o1[i] = 0; o2[i] = 0; }
     if (lane == 0) *rem = sr.n_free;
@@ -566,10 +569,34 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
     const int64_t step0 = (int64_t)(((uint64_t)a.step0_hi << 32) | a.step0_lo);
     const unsigned char *lg = log + (size_t)g * log_rows * log_pitch;
     int64_t e = half ? (int64_t)(limit ? limit[g] : n_steps) : 0; // steps [0, e) of the group's window are still to be visited
+    // All-binary models (one logged byte per step and row): the 4 bytes of my quad are one (unaligned) dword per row, and the
+    // rows' dwords simply add up (a byte is at most 16 chains, 4 rows at most 64: no carry between bytes).  The NEXT chunk's
+    // dwords are requested before the current chunk is walked -- their addresses do not depend on the scan stream --, so the
+    // one wavefront this group has on its SIMD no longer sits out a global-memory round trip per chunk.
+    typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
+    const bool packed_log = log_vals == 1u;
+    auto quad_ones = [&](const int64_t qlo) -> uint32_t { // sum over the rows of the 4 logged bytes of quad qlo + lane (steps outside the log: 0)
+        const int64_t k0 = (qlo + (int64_t)lane) * 4 - step0;
+        uint32_t sum = 0;
+        if (k0 >= 0 && k0 + 4 <= (int64_t)log_pitch) {
+            for (uint32_t r = 0; r < log_rows; ++r) sum += *reinterpret_cast<const u32_unaligned *>(lg + (size_t)r * log_pitch + (size_t)k0);
+        } else {
+            for (uint32_t j = 0; j < 4; ++j) {
+                const int64_t k = k0 + j;
+                if (k >= 0 && k < (int64_t)log_pitch)
+                    for (uint32_t r = 0; r < log_rows; ++r) sum += (uint32_t)lg[(size_t)r * log_pitch + (size_t)k] << (8u * j);
+            }
+        }
+        return sum;
+    };
+    uint32_t ones_next = 0;
+    if (packed_log && e > 0) ones_next = quad_ones(((step0 + e - 1) >> 2) - 63);
     while (e > 0 && *rem) {
         const int64_t qhi = (step0 + e - 1) >> 2, qlo = qhi - 63;
         { // (0) stage the chunk
             const int64_t q = qlo + lane;
+            const uint32_t ones = ones_next;
+            if (packed_log && qlo * 4 - step0 > 0) ones_next = quad_ones(qlo - 64); // the chunk after this one (walking backwards)
             uint32_t v[4] = {0, 0, 0, 0};
             if (q >= 0) sr.quad((uint64_t)q, v);
 #pragma unroll
@@ -577,6 +604,10 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
                 const int64_t k = q * 4 + j - step0;
                 const bool valid = k >= 0 && k < e;
                 cv[lane * 4u + j] = valid ? (unsigned short)v[j] : (unsigned short)0xffffu;
+                if (packed_log) {
+                    cl[lane * 4u + j] = valid ? (unsigned char)(ones >> (8u * j)) : (unsigned char)0;
+                    continue;
+                }
                 for (uint32_t c = 0; c < log_vals; ++c) {
                     uint32_t n1 = 0;
                     if (valid) for (uint32_t r = 0; r < log_rows; ++r) n1 += lg[(size_t)r * log_pitch + (size_t)k * log_vals + c];
@@ -615,9 +646,9 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
                 M[2] = j == 2 ? M[2] & bit : M[2]; M[3] = j == 3 ? M[3] & bit : M[3];
                 const uint32_t idx = (uint32_t)best, v = cv[idx], c = sn[v];
                 if (c < 2u * half) {
-                    uint32_t *o = (c < half ? o2 : o1) + a.hoff[v];
+                    uint32_t *o = (c < half ? o2 : o1) + hf[v];
                     if (log_vals == 1) { o[1] += cl[idx]; o[0] += 64u - cl[idx]; }
-                    else for (uint32_t x = 0; x < a.hoff[v + 1] - a.hoff[v]; ++x) o[x] += cl[idx * log_vals + x];
+                    else for (uint32_t x = 0; x < hf[v + 1] - hf[v]; ++x) o[x] += cl[idx * log_vals + x];
                     sn[v] = c + 1u;
                     full += (c + 1u == 2u * half) ? 1u : 0u;
                 }
@@ -718,7 +749,7 @@ hipError_t launch_stop_time(const ScanArgs &a, uint32_t cw, uint32_t batch, uint
 
 hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
                               uint32_t log_vals, const uint32_t *limit, uint32_t *hist, uint32_t *status, hipStream_t s) {
-    const size_t lds = ((size_t)a.n_vars + 2u * a.H + 1u) * sizeof(uint32_t) + 256u * sizeof(unsigned short) + 64u * 256u + 256u * log_vals;
+    const size_t lds = (2u * (size_t)a.n_vars + 2u * a.H + 2u) * sizeof(uint32_t) + 256u * sizeof(unsigned short) + 256u * log_vals;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ring_halves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ring_halves, dim3(a.n_groups), dim3(64), lds, s, a, n_steps, half, log, log_pitch, log_rows, log_vals, limit, hist, status);
