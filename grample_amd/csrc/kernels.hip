@@ -555,14 +555,17 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
                                                      uint32_t *status) {
     extern __shared__ uint32_t sm_scan[];
     const uint32_t n = a.n_vars, H = a.H, g = blockIdx.x, lane = threadIdx.x;
-    uint32_t *sn = sm_scan, *o1 = sn + n, *o2 = o1 + H, *hf = o2 + H, *rem = hf + n + 1u;
-    unsigned short *cv = reinterpret_cast<unsigned short *>(rem + 1);
-    unsigned char *cl = reinterpret_cast<unsigned char *>(cv + 256); // [256][log_vals]
+    uint32_t *sn = sm_scan, *o1 = sn + n, *o2 = o1 + H, *hf = o2 + H, *kc = hf + n + 1u, *rem = kc + n;
+    unsigned short *cv = reinterpret_cast<unsigned short *>(rem + 1), *fv = cv + 256; // fv[n]: the group's free list
+    unsigned char *cl = reinterpret_cast<unsigned char *>(fv + ((n + 1u) & ~1u)); // [256][log_vals]
     const ScanReplay sr(a, g);
+    // (the free list in LDS too: the scan replay indexes it with a Philox word, from global memory one more dependent round
+    // trip per chunk)
+    for (uint32_t i = lane; i < sr.n_free; i += 64u) fv[i] = (unsigned short)sr.freev[i];
     // (histogram offsets in LDS: the walk below looks one up per visited step, right between two LDS accesses -- from global
     // memory that dependent round trip was most of this kernel's time)
     for (uint32_t v = lane; v <= n; v += 64u) hf[v] = a.hoff[v];
-    for (uint32_t v = lane; v < n; v += 64u) sn[v] = 0;
+    for (uint32_t v = lane; v < n; v += 64u) { sn[v] = 0; kc[v] = 0; }
     for (uint32_t i = lane; i < H; i += 64u) { o1[i] = 0; o2[i] = 0; }
     if (lane == 0) *rem = sr.n_free;
     __syncthreads();
@@ -589,16 +592,30 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
         }
         return sum;
     };
-    uint32_t ones_next = 0;
-    if (packed_log && e > 0) ones_next = quad_ones(((step0 + e - 1) >> 2) - 63);
+    // the variables of quad q of the group's scan stream (ScanReplay::quad with the free list read from LDS)
+    auto quad_vars = [&](const int64_t q, uint32_t (&v)[4]) {
+        v[0] = v[1] = v[2] = v[3] = 0;
+        if (q < 0) return;
+        const u32x4 w = philox4x32_10((uint32_t)q, (uint32_t)((uint64_t)q >> 32), sr.gid, DOM_SCAN, sr.seed_lo, sr.seed_hi);
+        v[0] = fv[mul_hi_u32(w.x, sr.n_free)]; v[1] = fv[mul_hi_u32(w.y, sr.n_free)];
+        v[2] = fv[mul_hi_u32(w.z, sr.n_free)]; v[3] = fv[mul_hi_u32(w.w, sr.n_free)];
+    };
+    uint32_t ones_next = 0, v_next[4] = {0, 0, 0, 0};
+    if (e > 0) {
+        const int64_t qlo0 = ((step0 + e - 1) >> 2) - 63;
+        if (packed_log) ones_next = quad_ones(qlo0);
+        quad_vars(qlo0 + lane, v_next);
+    }
     while (e > 0 && *rem) {
         const int64_t qhi = (step0 + e - 1) >> 2, qlo = qhi - 63;
-        { // (0) stage the chunk
+        { // (0) stage the chunk; request / replay the one after it (walking backwards) before this one is walked
             const int64_t q = qlo + lane;
             const uint32_t ones = ones_next;
-            if (packed_log && qlo * 4 - step0 > 0) ones_next = quad_ones(qlo - 64); // the chunk after this one (walking backwards)
-            uint32_t v[4] = {0, 0, 0, 0};
-            if (q >= 0) sr.quad((uint64_t)q, v);
+            const uint32_t v[4] = {v_next[0], v_next[1], v_next[2], v_next[3]};
+            if (qlo * 4 - step0 > 0) {
+                if (packed_log) ones_next = quad_ones(qlo - 64);
+                quad_vars(qlo - 64 + lane, v_next);
+            }
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 const int64_t k = q * 4 + j - step0;
@@ -606,6 +623,14 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
                 cv[lane * 4u + j] = valid ? (unsigned short)v[j] : (unsigned short)0xffffu;
                 if (packed_log) {
                     cl[lane * 4u + j] = valid ? (unsigned char)(ones >> (8u * j)) : (unsigned char)0;
+                    continue;
+                }
+                if ((log_vals & 3u) == 0u) { // one count per value, 4 values per dword: the rows' dwords add up bytewise (no carries, see above)
+                    for (uint32_t c4 = 0; c4 < log_vals; c4 += 4u) {
+                        uint32_t n4 = 0;
+                        if (valid) for (uint32_t r = 0; r < log_rows; ++r) n4 += *reinterpret_cast<const uint32_t *>(lg + (size_t)r * log_pitch + (size_t)k * log_vals + c4);
+                        *reinterpret_cast<uint32_t *>(cl + (lane * 4u + j) * log_vals + c4) = n4;
+                    }
                     continue;
                 }
                 for (uint32_t c = 0; c < log_vals; ++c) {
@@ -616,23 +641,61 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
             }
         }
         __syncthreads();
-        // (1) which of the chunk's 256 steps are mine (variable mod 64 == lane): step (l, j) is owned by lane o = v & 63, so my
-        // mask over the 64 lanes of plane j is the AND over the 6 bits of o of "lanes whose bit b equals my bit b" -- 6 ballots
-        // per plane instead of every lane scanning all 256 entries (that scan was 90 % of this kernel: 11 ms per Grids_13 window)
-        unsigned long long M[4];
+        // (1) A variable's selections inside this chunk need their order only when the chunk straddles one of its two cuts
+        // (selection `half` or 2 * `half`, counted from the end of the window) -- at most two chunks per variable out of the
+        // hundreds a window has.  Everywhere else all of them fall into the same half (or are too old to count), so the 256
+        // steps are classified side by side: kc[v] = selections of v in this chunk (LDS atomics), sn[v] = selections in the
+        // newer chunks; fast steps add their counts with LDS atomics, only the steps of a straddling variable go through the
+        // ordered walk below.  (Walking every step in order was this kernel: ~12 dependent LDS round-trip chains per chunk.)
+        uint32_t mv[4];
+        bool slow[4], fast[4];
 #pragma unroll
         for (uint32_t j = 0; j < 4; ++j) {
-            const uint32_t v = cv[lane * 4u + j];
-            unsigned long long m = __ballot(v != 0xffffu);
-#pragma unroll
-            for (uint32_t b = 0; b < 6; ++b) {
-                const unsigned long long bb = __ballot((v >> b) & 1u);
-                m &= ((lane >> b) & 1u) ? bb : ~bb;
-            }
-            M[j] = m;
+            mv[j] = cv[lane * 4u + j];
+            if (mv[j] != 0xffffu) atomicAdd(&kc[mv[j]], 1u);
         }
-        // (2) walk my steps newest first (step index = 4 * lane + plane): the lanes walk side by side
+        __syncthreads();
         uint32_t full = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            slow[j] = fast[j] = false;
+            const uint32_t v = mv[j];
+            if (v == 0xffffu) continue;
+            const uint32_t c0 = sn[v], k = kc[v];
+            if (c0 >= 2u * half) continue;                        // its ring is full already
+            const bool second = c0 + k <= half, first = c0 >= half && c0 + k <= 2u * half;
+            if (!second && !first) { slow[j] = true; continue; } // the chunk straddles a cut of v
+            fast[j] = true;
+            uint32_t *o = (second ? o2 : o1) + hf[v];
+            const uint32_t idx = lane * 4u + j;
+            if (log_vals == 1) { atomicAdd(&o[1], (uint32_t)cl[idx]); atomicAdd(&o[0], 64u - cl[idx]); }
+            else for (uint32_t x = 0; x < hf[v + 1] - hf[v]; ++x) atomicAdd(&o[x], (uint32_t)cl[idx * log_vals + x]);
+        }
+        __syncthreads(); // every sn / kc of the chunk has been read
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint32_t v = mv[j];
+            if (v == 0xffffu) continue;
+            kc[v] = 0; // (every step of v writes the same 0)
+            if (fast[j]) full += (atomicAdd(&sn[v], 1u) + 1u == 2u * half) ? 1u : 0u; // exactly one step sees the ring fill up
+        }
+        // (2) the straddling variables' steps, in order: step (l, j) is owned by lane o = v & 63, so my mask over the 64 lanes of
+        // plane j is the AND over the 6 bits of o of "lanes whose bit b equals my bit b" -- 6 ballots per plane; then the lanes
+        // walk their steps newest first (step index = 4 * lane + plane), side by side: a variable is only ever touched by its owner
+        unsigned long long M[4] = {0, 0, 0, 0};
+        if (__any(slow[0] || slow[1] || slow[2] || slow[3])) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint32_t v = mv[j];
+                unsigned long long m = __ballot(slow[j]);
+#pragma unroll
+                for (uint32_t b = 0; b < 6; ++b) {
+                    const unsigned long long bb = __ballot((v >> b) & 1u);
+                    m &= ((lane >> b) & 1u) ? bb : ~bb;
+                }
+                M[j] = m;
+            }
+        }
         for (;;) {
             int best = -1;
 #pragma unroll
@@ -749,7 +812,7 @@ hipError_t launch_stop_time(const ScanArgs &a, uint32_t cw, uint32_t batch, uint
 
 hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
                               uint32_t log_vals, const uint32_t *limit, uint32_t *hist, uint32_t *status, hipStream_t s) {
-    const size_t lds = (2u * (size_t)a.n_vars + 2u * a.H + 2u) * sizeof(uint32_t) + 256u * sizeof(unsigned short) + 256u * log_vals;
+    const size_t lds = (3u * (size_t)a.n_vars + 2u * a.H + 2u) * sizeof(uint32_t) + (256u + (((size_t)a.n_vars + 1u) & ~(size_t)1)) * sizeof(unsigned short) + 256u * log_vals;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ring_halves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ring_halves, dim3(a.n_groups), dim3(64), lds, s, a, n_steps, half, log, log_pitch, log_rows, log_vals, limit, hist, status);
