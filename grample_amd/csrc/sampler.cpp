@@ -171,6 +171,16 @@ struct gr_sampler {
     DevBuf<unsigned char> d_state;
     DevBuf<unsigned long long> d_counts;
     DevBuf<unsigned long long> d_reduced; // gr_allreduce_counts: the cross-device total (scratch; d_counts is never overwritten)
+    // Scratch of the control-path calls, kept between calls like every other device buffer (an allocation and a free per
+    // call cost more than the kernels they serve, and a free synchronises the device): gr_collapse ...
+    DevBuf<uint32_t> cs_new_card, cs_fac_off, cs_fac_stride, cs_fac_tab;
+    DevBuf<int32_t> cs_new_fixed, cs_fac_pos;
+    DevBuf<double> cs_tables, cs_out, cs_part;
+    // ... gr_advance_chain ...
+    DevBuf<uint32_t> ac_out, ac_limit, ac_hist, ac_status, ac_hoff;
+    // ... gr_conditional
+    DevBuf<int32_t> cd_state;
+    DevBuf<double> cd_probs;
     std::vector<VariantDesc> h_variants;
     uint64_t step = 0, counted = 0;
     // adaptive sampler (N2): groups [0, n_active) run; the rest wait to be activated by gr_adapt
@@ -1175,9 +1185,9 @@ GR_VISIBLE int gr_collapse(gr_sampler *s, uint32_t variant, int32_t var_idx, int
         }
         const uint32_t n_entries = (uint32_t)post.Table.size();
         const uint32_t nblk = (n_entries + 255) / 256;
-        DevBuf<uint32_t> d_new_card, d_fac_off, d_fac_stride, d_fac_tab;
-        DevBuf<int32_t> d_new_fixed, d_fac_pos;
-        DevBuf<double> d_tables, d_out, d_part;
+        DevBuf<uint32_t> &d_new_card = s->cs_new_card, &d_fac_off = s->cs_fac_off, &d_fac_stride = s->cs_fac_stride, &d_fac_tab = s->cs_fac_tab;
+        DevBuf<int32_t> &d_new_fixed = s->cs_new_fixed, &d_fac_pos = s->cs_fac_pos;
+        DevBuf<double> &d_tables = s->cs_tables, &d_out = s->cs_out, &d_part = s->cs_part;
         d_new_card.upload(new_card, s->stream, s->stage); d_new_fixed.upload(new_fixed, s->stream, s->stage);
         d_fac_off.upload(fac_off, s->stream, s->stage); d_fac_pos.upload(fac_pos, s->stream, s->stage);
         d_fac_stride.upload(fac_stride, s->stream, s->stage); d_fac_tab.upload(fac_tab, s->stream, s->stage);
@@ -1504,7 +1514,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         // 1. how long: batches of 2N updates until every variable of every group has cw + 1 new samples (chain.go:184-215)
         const uint32_t batch = 2u * (uint32_t)s->n_vars;
         const uint32_t max_batches = (uint32_t)std::min<uint64_t>((1ull << 31) / batch, 1u << 20);
-        DevBuf<uint32_t> d_out;
+        DevBuf<uint32_t> &d_out = s->ac_out;
         d_out.alloc(n_groups);
         hip_check(launch_stop_time(a, cw, batch, max_batches, d_out.p, s->stream), "k_stop_time");
         std::vector<uint32_t> nb(n_groups);
@@ -1527,7 +1537,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         const size_t nH = (size_t)s->o.n_variants * s->H;
         DevBuf<unsigned char> &d_log = s->d_log;
         std::vector<uint64_t> c0(nH), c1(nH), c2(nH);
-        DevBuf<uint32_t> d_limit;
+        DevBuf<uint32_t> &d_limit = s->ac_limit;
         if (logging) {
             d_log.alloc((size_t)n_groups * rows * pitch); // (keeps a large enough allocation of an earlier window)
             hip_check(hipMemsetAsync(d_log.p, 0, (size_t)n_groups * rows * pitch, s->stream), "hipMemset");
@@ -1557,7 +1567,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         if (logging) {
             // 3. rebuild every ring's halves: the last 2 * (cw / 2) selections of each variable (circular.go:16-28)
             const uint32_t half = cw / 2u;
-            DevBuf<uint32_t> d_hist, d_status, d_hoff;
+            DevBuf<uint32_t> &d_hist = s->ac_hist, &d_status = s->ac_status, &d_hoff = s->ac_hoff;
             std::vector<uint32_t> hoff(s->n_vars + 1, 0);
             for (int v = 0; v < s->n_vars; ++v) hoff[v + 1] = hoff[v] + (uint32_t)s->card[v];
             d_hoff.upload(hoff, s->stream, s->stage);
@@ -1779,8 +1789,8 @@ GR_VISIBLE int gr_conditional(gr_sampler *s, uint32_t variant, int32_t v, const 
             if (state[u] < 0 || state[u] >= s->card[u]) throw Error(GR_E_INVALID, "state value out of range");
         s->use();
         if (s->dirty) s->rebuild();
-        DevBuf<int32_t> d_st;
-        DevBuf<double> d_pr;
+        DevBuf<int32_t> &d_st = s->cd_state;
+        DevBuf<double> &d_pr = s->cd_probs;
         d_st.upload(std::vector<int32_t>(state, state + s->n_vars), s->stream, s->stage);
         d_pr.alloc(var.Card);
         hip_check(launch_conditional(s->h_variants[variant], s->d_progs.p, s->d_prog_off.p, s->d_views.p, (uint32_t)v, d_st.p, d_pr.p, s->max_card, s->stream), "k_conditional");

@@ -502,16 +502,19 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     // The 16 chains of a step slot are one DPP row: row_shr 1,2,4,8 leave the number of ones in lane 15.
     unsigned char *logrow = LOG && p.log ? p.log + (size_t)(group * 4u + wave) * p.log_pitch + p.log_off : nullptr;
     // A step's value is written at its own level's pass; the counting happens once per step slot after the last pass
-    // (histogram adds commute): ones per slot = prefix popcount of the draw mask (V_MBCNT) minus the prefix at the end of
-    // the previous DPP row (row_bcast:15) -- valid in lane 15 of every row, the lane that adds to the histogram.
+    // (histogram adds commute).
+    // LOG: a group executes only the steps below its own stopping time `lim`.  The check is made per ITERATION (16 steps): the
+    // iterations entirely below it run the unchecked code (CHK = false), the one it cuts the per-step checks, and the loop ends
+    // there -- the later steps of the window leave the group untouched.
     uint32_t lim = 0xffffffffu; // LOG: the group's own stopping time inside the window (SweepParams::limit)
     if constexpr (LOG)
         if (p.limit) {
             const uint32_t t = p.limit[group];
             lim = t > p.log_off ? t - p.log_off : 0u;
         }
-    auto store = [&](const RecL<SLOTS, PACKED> &r, const bool val, const bool mine, const uint32_t sidx) {
-        if (mine && !(LOG && sidx >= lim)) lds[r.h.x + cb] = val ? (unsigned char)1 : (unsigned char)0;
+    auto store = [&](auto chk, const RecL<SLOTS, PACKED> &r, const bool val, const bool mine, const uint32_t sidx) {
+        constexpr bool CHK = LOG && decltype(chk)::value;
+        if (mine && !(CHK && sidx >= lim)) lds[r.h.x + cb] = val ? (unsigned char)1 : (unsigned char)0;
     };
     // The draws of a step are a wave mask (the compare's own result, in scalar registers; level passes merge masks with scalar
     // logic).  Ones of my step slot = popcount of the mask's 16 bits of my DPP row: (lo & rm_lo) | (hi & rm_hi) with two
@@ -521,18 +524,21 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     // SIMD every instruction of any kind costs an issue slot.  A DPP subtract (incl - incl of the previous row's lane 15 in
     // one instruction) does not exist: V_SUB and V_SUBREV with DPP both compute dpp(src0) - src1.]
     const uint32_t rm_lo = j < 2u ? 0xffffu << (16u * (j & 1u)) : 0u, rm_hi = j >= 2u ? 0xffffu << (16u * (j & 1u)) : 0u;
-    auto count = [&](const RecL<SLOTS, PACKED> &r, const unsigned long long drawn, const uint32_t sidx) {
+    auto count = [&](auto chk, const RecL<SLOTS, PACKED> &r, const unsigned long long drawn, const uint32_t sidx) {
+        constexpr bool CHK = LOG && decltype(chk)::value;
         if constexpr (COUNT) {
-            if (LOG && uni_b(sidx & ~3u) >= lim) return; // the whole quad is past the group's stopping time (limits are even,
+            if (CHK && uni_b(sidx & ~3u) >= lim) return; // the whole quad is past the group's stopping time (limits are even,
                                                          // so a quad is cut between its steps 1 and 2 at most)
-            if (tail && !(LOG && sidx >= lim)) {
+            if (tail && !(CHK && sidx >= lim)) {
                 const uint32_t s1 = (uint32_t)__builtin_popcount(((uint32_t)drawn & rm_lo) | ((uint32_t)(drawn >> 32) & rm_hi));
                 uint32_t zeros; // 16 - s1 (as C++ the compiler emits a negate and an add)
                 asm("v_sub_u32_e32 %0, 16, %1" : "=v"(zeros) : "v"(s1));
                 // (zeros, ones) of the variable are an aligned 8-byte pair of the rank-indexed histogram: one LDS atomic
                 __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>((uintptr_t)r.h.y),
                                        ((unsigned long long)s1 << 32) | zeros, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (LOG && logrow) logrow[sidx] = (unsigned char)s1;
+                // (MODE 2 is only launched with a log.  A buffer store -- row as the resource, quad as scalar offset, slot as a
+                // constant vector offset: no 64-bit address add -- measured 8 % SLOWER than this plain global store)
+                if constexpr (LOG) logrow[sidx] = (unsigned char)s1;
             }
         }
     };
@@ -577,7 +583,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     if constexpr (RECMODE == 2) { prefetch_plan(0); prefetch(rA, pwA); prefetch_plan(4); }
 
     // one iteration = 4 quads = 16 steps of every chain: (rc, pwc) hold its records and plan words, (rx, pwx) receive the next one's
-    auto iteration = [&](const uint32_t g0, RecL<SLOTS, PACKED> (&rc)[NREC], uint32_t (&pwc)[4], RecL<SLOTS, PACKED> (&rx)[NREC], uint32_t (&pwx)[4]) {
+    auto iteration = [&](auto chk, const uint32_t g0, RecL<SLOTS, PACKED> (&rc)[NREC], uint32_t (&pwc)[4], RecL<SLOTS, PACKED> (&rx)[NREC], uint32_t (&pwx)[4]) {
         if (RECMODE != 2 && (g0 & (kPlanChunk - 1u)) == kPlanChunk / 2u) {
             const uint32_t nc = g0 / kPlanChunk + 1u;
             if (nc < nchunks) {
@@ -635,13 +641,13 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
             const uint32_t sidx = (g0 + k) * 4u + j;
             const bool val = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
             unsigned long long drawn = __ballot(val); // the compare's own mask
-            store(r, val, pw[k] < kPlanLevelBit, sidx); // level 0: commit in the first pass
+            store(chk, r, val, pw[k] < kPlanLevelBit, sidx); // level 0: commit in the first pass
             if (__any(pw[k] >= kPlanDepsBit)) { // the quad has steps that do not commute (uniform: the same bit in its 4 words): re-gather after the lower levels committed
                 const uint32_t lv = (pw[k] >> 1) & 3u;
                 const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
                 auto again = [&](const uint32_t level) {
                     const bool v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
-                    store(r, v2, lv == level, sidx);
+                    store(chk, r, v2, lv == level, sidx);
                     const unsigned long long mine = __ballot(lv == level);
                     drawn = (drawn & ~mine) | (__ballot(v2) & mine);
                 };
@@ -651,16 +657,26 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
                     if (maxlv >= 3) again(3);
                 }
             }
-            count(r, drawn, sidx);
+            count(chk, r, drawn, sidx);
         }
+    };
+    // one iteration, checked against the group's stopping time only where it cuts it; false = the group is done
+    auto run = [&](const uint32_t g0, RecL<SLOTS, PACKED> (&rc)[NREC], uint32_t (&pwc)[4], RecL<SLOTS, PACKED> (&rx)[NREC], uint32_t (&pwx)[4]) -> bool {
+        if constexpr (LOG) {
+            if (g0 * 4u >= lim) return false;
+            if (g0 * 4u + 16u > lim) { iteration(std::true_type{}, g0, rc, pwc, rx, pwx); return false; }
+        }
+        iteration(std::false_type{}, g0, rc, pwc, rx, pwx);
+        return true;
     };
     if constexpr (RECMODE == 2) {
         for (uint32_t g0 = 0; g0 < nq; g0 += 8) {
-            iteration(g0, rA, pwA, rB, pwB);
-            if (g0 + 4u < nq) iteration(g0 + 4u, rB, pwB, rA, pwA);
+            if (!run(g0, rA, pwA, rB, pwB)) break;
+            if (g0 + 4u < nq && !run(g0 + 4u, rB, pwB, rA, pwA)) break;
         }
     } else {
-        for (uint32_t g0 = 0; g0 < nq; g0 += 4) iteration(g0, rA, pwA, rB, pwB);
+        for (uint32_t g0 = 0; g0 < nq; g0 += 4)
+            if (!run(g0, rA, pwA, rB, pwB)) break;
     }
 
     for (uint32_t v = j; v < p.n_vars; v += 4) p.state[(size_t)v * p.pitch + chain] = lds[v * p.par_stride + cb];
