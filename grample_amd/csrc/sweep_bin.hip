@@ -524,23 +524,27 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     // SIMD every instruction of any kind costs an issue slot.  A DPP subtract (incl - incl of the previous row's lane 15 in
     // one instruction) does not exist: V_SUB and V_SUBREV with DPP both compute dpp(src0) - src1.]
     const uint32_t rm_lo = j < 2u ? 0xffffu << (16u * (j & 1u)) : 0u, rm_hi = j >= 2u ? 0xffffu << (16u * (j & 1u)) : 0u;
-    auto count = [&](auto chk, const RecL<SLOTS, PACKED> &r, const unsigned long long drawn, const uint32_t sidx) {
+    // returns the ones of the step slot (the same in all 16 lanes of the row)
+    auto count = [&](auto chk, const RecL<SLOTS, PACKED> &r, const unsigned long long drawn, const uint32_t sidx) -> uint32_t {
         constexpr bool CHK = LOG && decltype(chk)::value;
+        uint32_t s1 = 0;
         if constexpr (COUNT) {
-            if (CHK && uni_b(sidx & ~3u) >= lim) return; // the whole quad is past the group's stopping time (limits are even,
-                                                         // so a quad is cut between its steps 1 and 2 at most)
+            if (CHK && uni_b(sidx & ~3u) >= lim) return 0u; // the whole quad is past the group's stopping time (limits are even,
+                                                            // so a quad is cut between its steps 1 and 2 at most)
+            s1 = (uint32_t)__builtin_popcount(((uint32_t)drawn & rm_lo) | ((uint32_t)(drawn >> 32) & rm_hi));
             if (tail && !(CHK && sidx >= lim)) {
-                const uint32_t s1 = (uint32_t)__builtin_popcount(((uint32_t)drawn & rm_lo) | ((uint32_t)(drawn >> 32) & rm_hi));
                 uint32_t zeros; // 16 - s1 (as C++ the compiler emits a negate and an add)
                 asm("v_sub_u32_e32 %0, 16, %1" : "=v"(zeros) : "v"(s1));
                 // (zeros, ones) of the variable are an aligned 8-byte pair of the rank-indexed histogram: one LDS atomic
                 __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>((uintptr_t)r.h.y),
                                        ((unsigned long long)s1 << 32) | zeros, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                // (MODE 2 is only launched with a log.  A buffer store -- row as the resource, quad as scalar offset, slot as a
-                // constant vector offset: no 64-bit address add -- measured 8 % SLOWER than this plain global store)
-                if constexpr (LOG) logrow[sidx] = (unsigned char)s1;
+                // (MODE 2 is only launched with a log.)  The iteration the stopping time cuts logs step by step; the others log
+                // their 16 steps with one store, below.  (A buffer store for the byte -- row as the resource, quad as scalar
+                // offset, slot as a constant vector offset: no 64-bit address add -- measured 8 % SLOWER than the plain store.)
+                if constexpr (CHK) logrow[sidx] = (unsigned char)s1;
             }
         }
+        return s1;
     };
 
     // RECMODE 2: records of the NEXT iteration, in flight while the current one runs
@@ -625,6 +629,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
                 for (int i = 0; i < (int)(sizeof(rq[k].s) / sizeof(uint4)); ++i) rq[k].s[i] = *reinterpret_cast<const uint4 *>(ra + 16 + 16 * i);
             }
         }
+        uint32_t ones_k[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             RecL<SLOTS, PACKED> r;
@@ -657,7 +662,21 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
                     if (maxlv >= 3) again(3);
                 }
             }
-            count(chk, r, drawn, sidx);
+            ones_k[k] = count(chk, r, drawn, sidx);
+        }
+        // LOG: the 16 logged bytes of the iteration -- step (g0 + k) * 4 + j, slot j's count of quad k sitting in row j's
+        // register k -- are 16 consecutive bytes.  The same two pairs of lane swaps that transpose the draws turn (register k,
+        // row j) into (register j, row k): every row then packs ITS quad's four bytes and its tail lane stores one dword, 4
+        // lanes = one 16-byte run per iteration instead of 16 single-byte stores (as many write requests: the logged sweep
+        // cost 20 % over the plain one, most of it there).
+        if constexpr (LOG && COUNT && !decltype(chk)::value) {
+            const auto a = __builtin_amdgcn_permlane32_swap(ones_k[0], ones_k[2], false, false);
+            const auto b = __builtin_amdgcn_permlane32_swap(ones_k[1], ones_k[3], false, false);
+            const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+            const auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+            const uint32_t quad_bytes = c[0] | (c[1] << 8) | (d[0] << 16) | (d[1] << 24);
+            typedef uint32_t __attribute__((aligned(1))) u32_unaligned; // (a window may start at any step)
+            if (tail) *reinterpret_cast<u32_unaligned *>(logrow + (size_t)(g0 + j) * 4u) = quad_bytes;
         }
     };
     // one iteration, checked against the group's stopping time only where it cuts it; false = the group is done
