@@ -651,6 +651,13 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
                 const uint32_t lv = (pw[k] >> 1) & 3u;
                 const uint32_t maxlv = uni_b(pw[k] >> 3) & 3u;
                 auto again = [&](const uint32_t level) {
+                    // The lanes of a wavefront talk to each other through the LDS state: this re-gather reads bytes that OTHER
+                    // lanes (the lower levels' step slots) have just committed.  The hardware keeps a wavefront's LDS operations
+                    // in order; the fence is for the COMPILER, which reasons per lane -- "this lane has not stored since it last
+                    // loaded these bytes, so loading them again is redundant unless it took the store branch" -- and did exactly
+                    // that when commit and re-gather once sat in one region: the re-gather ran only in the lanes that had just
+                    // stored, i.e. in none of those that needed it (caught by the counts hashes of scripts/dev_spread.py).
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     const bool v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
                     store(chk, r, v2, lv == level, sidx);
                     const unsigned long long mine = __ballot(lv == level);

@@ -196,6 +196,9 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
             const bool runs = !LOG || sidx < lim;                   // (limits are even: a quad is cut between its steps 1 and 2 at most)
             uint32_t val = 0;
             for (uint32_t pass = 0; pass <= maxlv; ++pass) {
+                // (a pass reads what OTHER lanes committed in the pass before: in-order LDS makes that work, the fence keeps the
+                // compiler from reasoning per lane about which of those loads are redundant -- see k_sweep_par4)
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 const bool mine = lv == pass && runs;
                 const uint32_t v2 = eval(h, u, mine);
                 if (mine) { *wr = (unsigned char)v2; val = v2; }

@@ -232,6 +232,10 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
             st[h.v * 64u] = (unsigned char)val;
             if (counting) atomicAdd(&hist[h.ho + val], 1u);
         }
+        // (the three other lanes of the chain read this byte in later steps: in-order LDS makes that work in hardware; the
+        // fence keeps the compiler, which reasons per lane, from treating a later load of it as redundant in the lanes
+        // that did not store -- see k_sweep_par4's re-gather)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     };
     // LOG: how many of the wavefront's 16 chains drew each value -- 4 ballots (one per bit of the 4-bit value, over the chains'
     // block-0 lanes); lane c (< 16) ANDs together, bit by bit, the ballot or its complement according to the bits of c, and
