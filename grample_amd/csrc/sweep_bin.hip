@@ -27,10 +27,17 @@
 #include "kernels.h"
 #include "philox.h"
 
+// This file is compiled five times (Makefile): GR_PAR4_PART 0 = everything but the instantiations of k_sweep_par4, parts
+// 1..4 = those, by record shape -- 330 instantiations of that kernel in one translation unit took four minutes to build.
+#ifndef GR_PAR4_PART
+#define GR_PAR4_PART 0
+#endif
+
 namespace gr {
 
 __device__ __forceinline__ uint32_t uni_b(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
+#if GR_PAR4_PART == 0
 // K0: scan plan.  One thread per (64-chain group, quad of steps); blockIdx.y = group.  The block first stages its
 // group's adjacency -- per selectable variable {id, neighbour count, neighbour ids} as u16 -- in LDS, so the
 // dependency tests below are LDS reads instead of chains of dependent global loads.
@@ -83,6 +90,7 @@ __global__ void __launch_bounds__(256) k_scan_plan(const FastParams p) {
     for (int j = 0; j < 4; ++j) out[j] |= maxlv << 3 | (maxlv ? kPlanDepsBit : 0u); // bits 3-4: highest level in the quad, in every word
     reinterpret_cast<uint4 *>(p.plan + (size_t)wave * p.plan_pitch)[qi] = make_uint4(out[0], out[1], out[2], out[3]);
 }
+#endif // GR_PAR4_PART == 0
 
 struct Rec {
     uint32_t w[kRecDwords];
@@ -802,6 +810,7 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
     }
 }
 
+#if GR_PAR4_PART == 0
 template <int SLOTS, bool PACKED>
 static hipError_t launch_strict_t(const FastParams &p, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s) {
     auto go = [&](auto kern) -> hipError_t {
@@ -829,6 +838,8 @@ hipError_t launch_sweep_strict(const FastParams &p, int slots, bool packed, uint
     }
 }
 
+#endif // GR_PAR4_PART == 0
+
 template <int SLOTS, bool PACKED>
 static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t lds, hipStream_t s) {
     auto go = [&](auto kern) -> hipError_t {
@@ -851,21 +862,9 @@ static hipError_t launch_par_t(const FastParams &p, uint32_t blocks, uint32_t ld
     return !p.counting ? go(&k_sweep_par4<SLOTS, PACKED, 0, 0>) : p.log ? go(&k_sweep_par4<SLOTS, PACKED, 2, 0>) : go(&k_sweep_par4<SLOTS, PACKED, 1, 0>);
 }
 
-hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t lds, hipStream_t s) {
-    if (packed) // one dword per neighbour: fewer LDS bytes per step, this form's bottleneck
-        switch (slots) {
-        case 0: case 1: return launch_par_t<1, true>(p, blocks, lds, s);
-        case 2: return launch_par_t<2, true>(p, blocks, lds, s);
-        case 3: return launch_par_t<3, true>(p, blocks, lds, s);
-        case 4: return launch_par_t<4, true>(p, blocks, lds, s);
-        case 5: return launch_par_t<5, true>(p, blocks, lds, s);
-        case 6: return launch_par_t<6, true>(p, blocks, lds, s);
-        case 13: return launch_par_t<13, true>(p, blocks, lds, s); // 128-byte records (rec_stride = 128)
-        case 14: return launch_par_t<14, true>(p, blocks, lds, s);
-        case 15: return launch_par_t<15, true>(p, blocks, lds, s);
-        case 16: return launch_par_t<16, true>(p, blocks, lds, s);
-        default: break;
-        }
+// the instantiations, one translation unit per record shape
+#if GR_PAR4_PART == 1
+hipError_t launch_sweep_par4_p1(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s) { // unpacked, 1..6 neighbours
     switch (slots) {
     case 0: case 1: return launch_par_t<1, false>(p, blocks, lds, s);
     case 2: return launch_par_t<2, false>(p, blocks, lds, s);
@@ -873,6 +872,24 @@ hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32
     case 4: return launch_par_t<4, false>(p, blocks, lds, s);
     case 5: return launch_par_t<5, false>(p, blocks, lds, s);
     case 6: return launch_par_t<6, false>(p, blocks, lds, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+#elif GR_PAR4_PART == 2
+hipError_t launch_sweep_par4_p2(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s) { // packed, 1..6 neighbours
+    switch (slots) {
+    case 0: case 1: return launch_par_t<1, true>(p, blocks, lds, s);
+    case 2: return launch_par_t<2, true>(p, blocks, lds, s);
+    case 3: return launch_par_t<3, true>(p, blocks, lds, s);
+    case 4: return launch_par_t<4, true>(p, blocks, lds, s);
+    case 5: return launch_par_t<5, true>(p, blocks, lds, s);
+    case 6: return launch_par_t<6, true>(p, blocks, lds, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+#elif GR_PAR4_PART == 3
+hipError_t launch_sweep_par4_p3(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s) { // packed, 7..12 neighbours
+    switch (slots) {
     case 7: return launch_par_t<7, true>(p, blocks, lds, s);
     case 8: return launch_par_t<8, true>(p, blocks, lds, s);
     case 9: return launch_par_t<9, true>(p, blocks, lds, s);
@@ -881,6 +898,29 @@ hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32
     case 12: return launch_par_t<12, true>(p, blocks, lds, s);
     default: return hipErrorInvalidValue;
     }
+}
+#elif GR_PAR4_PART == 4
+hipError_t launch_sweep_par4_p4(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s) { // packed, 128-byte records (rec_stride = 128)
+    switch (slots) {
+    case 13: return launch_par_t<13, true>(p, blocks, lds, s);
+    case 14: return launch_par_t<14, true>(p, blocks, lds, s);
+    case 15: return launch_par_t<15, true>(p, blocks, lds, s);
+    case 16: return launch_par_t<16, true>(p, blocks, lds, s);
+    default: return hipErrorInvalidValue;
+    }
+}
+#else
+hipError_t launch_sweep_par4_p1(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s);
+hipError_t launch_sweep_par4_p2(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s);
+hipError_t launch_sweep_par4_p3(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s);
+hipError_t launch_sweep_par4_p4(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s);
+
+hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    if (slots > 16) return hipErrorInvalidValue;
+    if (slots > 12) return launch_sweep_par4_p4(p, slots, blocks, lds, s);
+    if (slots > 6) return launch_sweep_par4_p3(p, slots, blocks, lds, s);
+    // packed: one dword per neighbour -- fewer record bytes per step
+    return packed ? launch_sweep_par4_p2(p, slots, blocks, lds, s) : launch_sweep_par4_p1(p, slots, blocks, lds, s);
 }
 
 template <int SLOTS, bool PACKED>
@@ -921,5 +961,7 @@ hipError_t launch_sweep_bin(const FastParams &p, int slots, uint32_t blocks, uin
     default: return hipErrorInvalidValue;
     }
 }
+
+#endif // GR_PAR4_PART
 
 } // namespace gr
