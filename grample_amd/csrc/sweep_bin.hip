@@ -336,7 +336,7 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
 //   lanes     lane = j * 16 + c: a 16-lane LDS lane group / DPP row is one step slot
 //   draws     lane (j, c) computes Philox for quad 4*SQ + j of chain c; two pairs of gfx950 lane swaps transpose
 //             the 4x4 words so that lane (j, c) ends up with word j of quads 4*SQ .. 4*SQ+3
-//   counts    DPP row reduction of the 16 draws of a step slot, then one lane adds (zeros, ones)
+//   counts    popcount of the compare mask's 16 bits of a step slot's DPP row; its lane 15 adds (zeros, ones) with one 64-bit LDS atomic
 constexpr uint32_t kParStride = 80;
 
 // LDS accesses by absolute LDS address.  The dynamic LDS array's base is a link-time symbol, so `lds + x` costs a
