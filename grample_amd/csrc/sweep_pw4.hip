@@ -265,17 +265,19 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
         const u32x2v sv = plan[q - (step0 >> 2)]; // the quad's four variables, 16 bits each
         const uint32_t sc[4] = {sv[0] & 0xffffu, sv[0] >> 16, sv[1] & 0xffffu, sv[1] >> 16};
         const u32x4 dr = philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
+        // step index inside the launch, as 32 bits: a step before step0 (first quad of a quad-unaligned launch) wraps to a huge
+        // value, so ONE unsigned scalar compare against the launch length covers both ends (64-bit compares are VALU work)
+        const uint32_t rel0 = (uint32_t)((q << 2) - step0);
         int j = 0;
 #pragma unroll 1
         while (j < 4) {
-            const uint64_t s = (q << 2) + j;
-            if (s < step0 || s >= step1) { ++j; continue; }
-            const uint32_t sidx = (uint32_t)(s - step0);
+            const uint32_t sidx = rel0 + (uint32_t)j;
+            if (sidx >= p.n_steps) { ++j; continue; }
             if (LOG && sidx >= lim) { ++j; continue; } // the group has finished its AdvanceChain: nothing changes any more
             const StepHdr ha = header(j == 0 ? sc[0] : j == 1 ? sc[1] : j == 2 ? sc[2] : sc[3]); // (no register arrays indexed by j)
             const uint32_t dua = j == 0 ? dr.x : j == 1 ? dr.y : j == 2 ? dr.z : dr.w;
             // the next step runs together with this one when it exists and its variable is neither this one nor a neighbour
-            bool pair = j < 3 && s + 1 < step1 && (!LOG || sidx + 1u < lim);
+            bool pair = j < 3 && sidx + 1u < p.n_steps && (!LOG || sidx + 1u < lim);
             StepHdr hb = ha;
             if (pair) {
                 hb = header(j == 0 ? sc[1] : j == 1 ? sc[2] : sc[3]);
