@@ -506,39 +506,56 @@ __global__ void __launch_bounds__(256) k_scan_vars(const ScanArgs a, uint32_t n_
 // AdvanceChain's stopping rule (chain.go:184-215): batches of `batch` (= 2 N) updates until every selectable
 // variable of the group has been selected cw + 1 more times.  out[group] = number of batches.
 // One wavefront per group; selection counters in LDS (n_vars words).
-__global__ __launch_bounds__(64) void k_stop_time(const ScanArgs a, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *out) {
+__global__ __launch_bounds__(256) void k_stop_time(const ScanArgs a, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *out) {
     extern __shared__ uint32_t sm_scan[];
-    uint32_t *cnt = sm_scan;
-    const uint32_t g = blockIdx.x, lane = threadIdx.x;
+    uint32_t *cnt = sm_scan;                    // [n_vars] selections so far
+    unsigned short *fv = reinterpret_cast<unsigned short *>(cnt + a.n_vars); // the group's free list (the replay indexes it with a Philox word)
+    const uint32_t g = blockIdx.x, tid = threadIdx.x, T = blockDim.x;
     const ScanReplay sr(a, g);
-    for (uint32_t v = lane; v < a.n_vars; v += 64u) cnt[v] = 0;
+    for (uint32_t v = tid; v < a.n_vars; v += T) cnt[v] = 0;
+    for (uint32_t i = tid; i < sr.n_free; i += T) fv[i] = (unsigned short)sr.freev[i];
     __syncthreads();
-    // (cw + 1) * n_free selections are needed in all: no batch before that many steps can be the last one
-    const uint64_t need_steps = (uint64_t)(cw + 1u) * sr.n_free;
-    uint64_t s = ((uint64_t)a.step0_hi << 32) | a.step0_lo;
-    uint32_t b = 0;
-    bool done = sr.n_free == 0;
-    while (b < max_batches && !done) {
-        const uint64_t e = s + batch;
-        for (uint64_t q = (s >> 2) + lane; q <= ((e - 1u) >> 2); q += 64u) {
-            uint32_t v[4];
-            sr.quad(q, v);
+    // count the selections of steps [s, e): 4 wavefronts, one quad of the scan stream per lane and trip
+    auto count_range = [&](const uint64_t s, const uint64_t e) {
+        for (uint64_t q = (s >> 2) + tid; q <= ((e - 1u) >> 2); q += T) {
+            const u32x4 w = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), sr.gid, DOM_SCAN, sr.seed_lo, sr.seed_hi);
+            const uint32_t v[4] = {fv[mul_hi_u32(w.x, sr.n_free)], fv[mul_hi_u32(w.y, sr.n_free)], fv[mul_hi_u32(w.z, sr.n_free)],
+                                   fv[mul_hi_u32(w.w, sr.n_free)]};
 #pragma unroll
             for (uint32_t j = 0; j < 4; ++j) {
                 const uint64_t st = q * 4u + j;
                 if (st >= s && st < e) atomicAdd(&cnt[v[j]], 1u);
             }
         }
+    };
+    // (cw + 1) * n_free selections are needed in all: no batch before that many steps can be the last one, so the batches up
+    // to there are counted in one go (no barrier, no check per batch)
+    const uint64_t need_steps = (uint64_t)(cw + 1u) * sr.n_free;
+    uint64_t s = ((uint64_t)a.step0_hi << 32) | a.step0_lo;
+    uint32_t b = 0;
+    bool done = sr.n_free == 0;
+    if (!done && batch) {
+        const uint64_t bulk = std::min<uint64_t>(need_steps / batch, max_batches);
+        if (bulk > 1u) {
+            b = (uint32_t)(bulk - 1u); // (the batch that reaches need_steps is checked like every later one)
+            count_range(s, s + (uint64_t)b * batch);
+            s += (uint64_t)b * batch;
+            __syncthreads();
+        }
+    }
+    while (b < max_batches && !done) {
+        const uint64_t e = s + batch;
+        count_range(s, e);
         s = e;
         b++;
         __syncthreads();
         if ((uint64_t)b * batch >= need_steps) {
             bool need = false;
-            for (uint32_t i = lane; i < sr.n_free; i += 64u) need = need || cnt[sr.freev[i]] < cw + 1u;
-            done = __ballot(need) == 0ull;
+            for (uint32_t i = tid; i < sr.n_free; i += T) need = need || cnt[fv[i]] < cw + 1u;
+            done = __syncthreads_or(need ? 1 : 0) == 0;
         }
     }
-    if (lane == 0) out[g] = done ? b : 0xffffffffu;
+    if (tid == 0) out[g] = done ? b : 0xffffffffu;
 }
 
 // ChainHistory's two halves (buffer/circular.go:54-84, chain.go:270-277), rebuilt from the draw log: walking the
@@ -550,11 +567,43 @@ __global__ __launch_bounds__(64) void k_stop_time(const ScanArgs a, uint32_t cw,
 // (variable, counts) per step in LDS; (1) every lane lists, newest first, the steps whose variable it owns
 // (v mod 64 == lane); (2) the lanes walk their lists side by side -- a variable is only ever touched by its owner,
 // so the per-variable order of the serial walk is kept without atomics.
+// A long window is cut into `n_seg` SEGMENTS of `seg_chunks` chunks (counted from the end of the group's window), one block
+// each: the one wavefront per group this kernel used to be leaves most of the chip idle and pays every latency in full.  A
+// segment needs to know how often each variable was selected in the NEWER segments -- k_ring_count, a first pass over the scan
+// stream alone -- and adds its two histograms to the group's with atomics.  hist must be zero on entry.
+__global__ __launch_bounds__(64) void k_ring_count(const ScanArgs a, uint32_t n_steps, const uint32_t *limit, uint32_t n_seg, uint32_t seg_chunks,
+                                                    uint32_t *seg_cnt /*[n_groups][n_seg][n_vars]*/) {
+    extern __shared__ uint32_t sm_scan[];
+    const uint32_t n = a.n_vars, g = blockIdx.x, seg = blockIdx.y, lane = threadIdx.x;
+    uint32_t *cnt = sm_scan;
+    const ScanReplay sr(a, g);
+    for (uint32_t v = lane; v < n; v += 64u) cnt[v] = 0;
+    __syncthreads();
+    const int64_t step0 = (int64_t)(((uint64_t)a.step0_hi << 32) | a.step0_lo);
+    const int64_t E = (int64_t)(limit ? limit[g] : n_steps);
+    if (E > 0) {
+        const int64_t qhi0 = (step0 + E - 1) >> 2;
+        for (uint32_t c = seg * seg_chunks; c < (seg + 1u) * seg_chunks; ++c) {
+            const int64_t q = qhi0 - 64 * (int64_t)c - 63 + (int64_t)lane;
+            if ((qhi0 - 64 * (int64_t)c) * 4 + 3 - step0 < 0) break; // the chunk lies before the window
+            uint32_t v[4] = {0, 0, 0, 0};
+            if (q >= 0) sr.quad((uint64_t)q, v);
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const int64_t k = q * 4 + j - step0;
+                if (k >= 0 && k < E) atomicAdd(&cnt[v[j]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t v = lane; v < n; v += 64u) seg_cnt[((size_t)g * n_seg + seg) * n + v] = cnt[v];
+}
+
 __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch,
                                                      uint32_t log_rows, uint32_t log_vals, const uint32_t *limit /*[n_groups] or null*/, uint32_t *hist /*[n_groups][2][H]*/,
-                                                     uint32_t *status) {
+                                                     uint32_t *status, uint32_t n_seg, uint32_t seg_chunks, const uint32_t *seg_cnt) {
     extern __shared__ uint32_t sm_scan[];
-    const uint32_t n = a.n_vars, H = a.H, g = blockIdx.x, lane = threadIdx.x;
+    const uint32_t n = a.n_vars, H = a.H, g = blockIdx.x, seg = blockIdx.y, lane = threadIdx.x;
     uint32_t *sn = sm_scan, *o1 = sn + n, *o2 = o1 + H, *hf = o2 + H, *kc = hf + n + 1u, *rem = kc + n;
     unsigned short *cv = reinterpret_cast<unsigned short *>(rem + 1), *fv = cv + 256; // fv[n]: the group's free list
     unsigned char *cl = reinterpret_cast<unsigned char *>(fv + ((n + 1u) & ~1u)); // [256][log_vals]
@@ -565,13 +614,43 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
     // (histogram offsets in LDS: the walk below looks one up per visited step, right between two LDS accesses -- from global
     // memory that dependent round trip was most of this kernel's time)
     for (uint32_t v = lane; v <= n; v += 64u) hf[v] = a.hoff[v];
-    for (uint32_t v = lane; v < n; v += 64u) { sn[v] = 0; kc[v] = 0; }
+    for (uint32_t v = lane; v < n; v += 64u) { // selections in the newer segments
+        uint32_t c = 0;
+        for (uint32_t t = 0; t < seg; ++t) c += seg_cnt[((size_t)g * n_seg + t) * n + v];
+        sn[v] = c;
+        kc[v] = 0;
+    }
     for (uint32_t i = lane; i < H; i += 64u) { o1[i] = 0; o2[i] = 0; }
-    if (lane == 0) *rem = sr.n_free;
+    if (lane == 0) *rem = 0;
+    __syncthreads();
+    { // rings not yet full when this segment starts
+        uint32_t open = 0;
+        for (uint32_t i = lane; i < sr.n_free; i += 64u) open += sn[fv[i]] < 2u * half ? 1u : 0u;
+        if (open) atomicAdd(rem, open);
+    }
+    if (seg == 0 && n_seg > 1u) { // the window's verdict needs every segment's counts: rings that never fill
+        uint32_t open = 0;
+        for (uint32_t i = lane; i < sr.n_free; i += 64u) {
+            uint32_t c = 0;
+            for (uint32_t t = 0; t < n_seg; ++t) c += seg_cnt[((size_t)g * n_seg + t) * n + fv[i]];
+            open += c < 2u * half ? 1u : 0u;
+        }
+        if (open && half) atomicAdd(&status[g], open); // (status is zero on entry)
+    }
     __syncthreads();
     const int64_t step0 = (int64_t)(((uint64_t)a.step0_hi << 32) | a.step0_lo);
     const unsigned char *lg = log + (size_t)g * log_rows * log_pitch;
-    int64_t e = half ? (int64_t)(limit ? limit[g] : n_steps) : 0; // steps [0, e) of the group's window are still to be visited
+    const int64_t E = half ? (int64_t)(limit ? limit[g] : n_steps) : 0;
+    // this segment: chunks [seg * seg_chunks, (seg + 1) * seg_chunks) counted from the end of the window; e = steps [0, e) still
+    // to be visited when it starts, e_end = where the next (older) segment takes over
+    int64_t e = E, e_end = 0;
+    if (E > 0) {
+        const int64_t qhi0 = (step0 + E - 1) >> 2;
+        if (seg > 0) e = (qhi0 - 64 * (int64_t)(seg * seg_chunks) + 1) * 4 - step0;
+        e_end = (qhi0 - 64 * (int64_t)((seg + 1u) * seg_chunks) + 1) * 4 - step0;
+        if (e_end < 0) e_end = 0;
+        if (e < 0) e = 0;
+    }
     // All-binary models (one logged byte per step and row): the 4 bytes of my quad are one (unaligned) dword per row, and the
     // rows' dwords simply add up (a byte is at most 16 chains, 4 rows at most 64: no carry between bytes).  The NEXT chunk's
     // dwords are requested before the current chunk is walked -- their addresses do not depend on the scan stream --, so the
@@ -601,18 +680,18 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
         v[2] = fv[mul_hi_u32(w.z, sr.n_free)]; v[3] = fv[mul_hi_u32(w.w, sr.n_free)];
     };
     uint32_t ones_next = 0, v_next[4] = {0, 0, 0, 0};
-    if (e > 0) {
+    if (e > e_end) {
         const int64_t qlo0 = ((step0 + e - 1) >> 2) - 63;
         if (packed_log) ones_next = quad_ones(qlo0);
         quad_vars(qlo0 + lane, v_next);
     }
-    while (e > 0 && *rem) {
+    while (e > e_end && *rem) {
         const int64_t qhi = (step0 + e - 1) >> 2, qlo = qhi - 63;
         { // (0) stage the chunk; request / replay the one after it (walking backwards) before this one is walked
             const int64_t q = qlo + lane;
             const uint32_t ones = ones_next;
             const uint32_t v[4] = {v_next[0], v_next[1], v_next[2], v_next[3]};
-            if (qlo * 4 - step0 > 0) {
+            if (qlo * 4 - step0 > e_end) {
                 if (packed_log) ones_next = quad_ones(qlo - 64);
                 quad_vars(qlo - 64 + lane, v_next);
             }
@@ -722,11 +801,11 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
         e = qlo * 4 - step0; // everything from quad qlo on is done
     }
     __syncthreads();
-    for (uint32_t i = lane; i < H; i += 64u) {
-        hist[((size_t)g * 2u + 0u) * H + i] = o1[i];
-        hist[((size_t)g * 2u + 1u) * H + i] = o2[i];
+    for (uint32_t i = lane; i < H; i += 64u) { // (hist is zero on entry; one block per segment adds its share)
+        if (o1[i]) atomicAdd(&hist[((size_t)g * 2u + 0u) * H + i], o1[i]);
+        if (o2[i]) atomicAdd(&hist[((size_t)g * 2u + 1u) * H + i], o2[i]);
     }
-    if (lane == 0) status[g] = half ? *rem : 0u;
+    if (n_seg == 1u && lane == 0 && half) status[g] = *rem; // (several segments: the verdict comes from the counts, above)
 }
 
 // ------------------------------------------------------------ host launchers
@@ -806,16 +885,34 @@ hipError_t launch_scan_vars(const ScanArgs &a, uint32_t n_quads, uint32_t pitch_
 }
 
 hipError_t launch_stop_time(const ScanArgs &a, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_stop_time, dim3(a.n_groups), dim3(64), a.n_vars * sizeof(uint32_t), s, a, cw, batch, max_batches, out);
+    const size_t lds = (size_t)a.n_vars * sizeof(uint32_t) + (((size_t)a.n_vars + 1u) & ~(size_t)1) * sizeof(unsigned short);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stop_time), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_stop_time, dim3(a.n_groups), dim3(256), lds, s, a, cw, batch, max_batches, out);
     return hipGetLastError();
 }
 
 hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
-                              uint32_t log_vals, const uint32_t *limit, uint32_t *hist, uint32_t *status, hipStream_t s) {
+                              uint32_t log_vals, const uint32_t *limit, uint32_t *hist, uint32_t *status, uint32_t n_seg, uint32_t seg_chunks,
+                              uint32_t *seg_cnt, hipStream_t s) {
+    // hist and status are accumulated into: zero them; with several segments the per-segment selection counts come first
+    hipError_t e0 = hipMemsetAsync(hist, 0, (size_t)a.n_groups * 2u * a.H * sizeof(uint32_t), s);
+    if (e0 != hipSuccess) return e0;
+    e0 = hipMemsetAsync(status, 0, (size_t)a.n_groups * sizeof(uint32_t), s);
+    if (e0 != hipSuccess) return e0;
+    if (n_seg > 1u) {
+        const size_t lc = (size_t)a.n_vars * sizeof(uint32_t);
+        e0 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ring_count), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lc);
+        if (e0 != hipSuccess) return e0;
+        hipLaunchKernelGGL(k_ring_count, dim3(a.n_groups, n_seg), dim3(64), lc, s, a, n_steps, limit, n_seg, seg_chunks, seg_cnt);
+        e0 = hipGetLastError();
+        if (e0 != hipSuccess) return e0;
+    }
     const size_t lds = (3u * (size_t)a.n_vars + 2u * a.H + 2u) * sizeof(uint32_t) + (256u + (((size_t)a.n_vars + 1u) & ~(size_t)1)) * sizeof(unsigned short) + 256u * log_vals;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ring_halves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_ring_halves, dim3(a.n_groups), dim3(64), lds, s, a, n_steps, half, log, log_pitch, log_rows, log_vals, limit, hist, status);
+    hipLaunchKernelGGL(k_ring_halves, dim3(a.n_groups, n_seg), dim3(64), lds, s, a, n_steps, half, log, log_pitch, log_rows, log_vals, limit, hist, status,
+                       n_seg, seg_chunks, seg_cnt);
     return hipGetLastError();
 }
 

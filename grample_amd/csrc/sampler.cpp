@@ -177,7 +177,7 @@ struct gr_sampler {
     DevBuf<int32_t> cs_new_fixed, cs_fac_pos;
     DevBuf<double> cs_tables, cs_out, cs_part;
     // ... gr_advance_chain ...
-    DevBuf<uint32_t> ac_out, ac_limit, ac_hist, ac_status, ac_hoff;
+    DevBuf<uint32_t> ac_out, ac_limit, ac_hist, ac_status, ac_hoff, ac_segcnt;
     // ... gr_conditional
     DevBuf<int32_t> cd_state;
     DevBuf<double> cd_probs;
@@ -1574,7 +1574,15 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
             a.hoff = d_hoff.p; a.H = (uint32_t)s->H;
             d_hist.alloc((size_t)n_groups * 2u * s->H);
             d_status.alloc(n_groups);
-            hip_check(launch_ring_halves(a, (uint32_t)L, half, d_log.p, (uint32_t)pitch, rows, log_vals, d_limit.p, d_hist.p, d_status.p, s->stream), "k_ring_halves");
+            // one block per group and SEGMENT of the window: enough of them to fill the chip (a lone wavefront per group paid
+            // every latency in full: 8 ms for the 512 groups x 500 000 steps of the reference's adaptive experiment)
+            const uint32_t n_chunks = (uint32_t)((L + 3u + 255u) / 256u + 1u); // 256-step chunks, counted from the end of the window
+            uint32_t n_seg = std::min<uint32_t>({16u, std::max(1u, 4096u / n_groups), std::max(1u, n_chunks / 4u)});
+            const uint32_t seg_chunks = (n_chunks + n_seg - 1u) / n_seg;
+            n_seg = (n_chunks + seg_chunks - 1u) / seg_chunks;
+            if (n_seg > 1u) s->ac_segcnt.alloc((size_t)n_groups * n_seg * (size_t)s->n_vars);
+            hip_check(launch_ring_halves(a, (uint32_t)L, half, d_log.p, (uint32_t)pitch, rows, log_vals, d_limit.p, d_hist.p, d_status.p, n_seg, seg_chunks,
+                                         s->ac_segcnt.p, s->stream), "k_ring_halves");
             std::vector<uint32_t> hist((size_t)n_groups * 2u * s->H), status(n_groups);
             s->download(hist.data(), d_hist.p, hist.size() * sizeof(uint32_t));
             s->download(status.data(), d_status.p, n_groups * sizeof(uint32_t));
