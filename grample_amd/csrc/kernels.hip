@@ -28,6 +28,12 @@
 #include "philox.h"
 #include "cond.h"
 
+// Compiled three times (Makefile): GR_KSWEEP_PART 0 = everything, with the instantiations of k_sweep for Card <= 4 only;
+// parts 1 and 2 = the instantiations for Card <= 16 and Card <= 64 (72 of them in one translation unit took two minutes).
+#ifndef GR_KSWEEP_PART
+#define GR_KSWEEP_PART 0
+#endif
+
 namespace gr {
 
 // ------------------------------------------------------------------ helpers
@@ -342,6 +348,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     }
 }
 
+#if GR_KSWEEP_PART == 0
 // K3: start state (gibbs-simple.go:84-112 / 132-142): evidence value, else
 // uniform over [0, Card).  `epoch` separates the re-draw after a collapse.
 __global__ void k_init_state(unsigned char *state, const int32_t *card, const int32_t *fixed, uint32_t n_vars, uint32_t pitch,
@@ -808,6 +815,8 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
     if (n_seg == 1u && lane == 0 && half) status[g] = *rem; // (several segments: the verdict comes from the counts, above)
 }
 
+#endif // GR_KSWEEP_PART == 0
+
 // ------------------------------------------------------------ host launchers
 #define GR_DISPATCH_MAXC(maxc, ...)                       \
     do {                                                    \
@@ -828,26 +837,49 @@ static hipError_t launch_sweep_t(const SweepParams &p, uint32_t blocks, uint32_t
     return hipGetLastError();
 }
 
+template <int MC>
+static hipError_t launch_sweep_mc(const SweepParams &p, bool cpt, bool tab_lds, bool pairwise, bool per_chain, bool state_global,
+                                  uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t s) {
+    if (state_global) // state in global memory: tables from global memory too; no strict mode, no draw log
+        return (p.log || per_chain || tab_lds) ? hipErrorInvalidValue
+               : cpt ? launch_sweep_t<MC, true, false, false, false, false, true>(p, blocks, threads, lds_bytes, s)
+               : pairwise ? launch_sweep_t<MC, false, false, true, false, false, true>(p, blocks, threads, lds_bytes, s)
+                          : launch_sweep_t<MC, false, false, false, false, false, true>(p, blocks, threads, lds_bytes, s);
+    if (p.log) return (per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, false, true>(p, blocks, threads, lds_bytes, s);
+    if (per_chain) return tab_lds ? launch_sweep_t<MC, false, true, false, true>(p, blocks, threads, lds_bytes, s)
+                                  : launch_sweep_t<MC, false, false, false, true>(p, blocks, threads, lds_bytes, s);
+    if (cpt) return tab_lds ? launch_sweep_t<MC, true, true, false>(p, blocks, threads, lds_bytes, s)
+                            : launch_sweep_t<MC, true, false, false>(p, blocks, threads, lds_bytes, s);
+    if (pairwise) return tab_lds ? launch_sweep_t<MC, false, true, true>(p, blocks, threads, lds_bytes, s)
+                                 : launch_sweep_t<MC, false, false, true>(p, blocks, threads, lds_bytes, s);
+    return tab_lds ? launch_sweep_t<MC, false, true, false>(p, blocks, threads, lds_bytes, s)
+                   : launch_sweep_t<MC, false, false, false>(p, blocks, threads, lds_bytes, s);
+}
+
+#if GR_KSWEEP_PART == 1
+hipError_t launch_sweep_card16(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, bool per_chain, bool state_global,
+                               uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t s) {
+    return max_card <= 8 ? launch_sweep_mc<8>(p, cpt, tab_lds, pairwise, per_chain, state_global, blocks, threads, lds_bytes, s)
+                         : launch_sweep_mc<16>(p, cpt, tab_lds, pairwise, per_chain, state_global, blocks, threads, lds_bytes, s);
+}
+#elif GR_KSWEEP_PART == 2
+hipError_t launch_sweep_card64(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, bool per_chain, bool state_global,
+                               uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t s) {
+    return max_card <= 32 ? launch_sweep_mc<32>(p, cpt, tab_lds, pairwise, per_chain, state_global, blocks, threads, lds_bytes, s)
+                          : launch_sweep_mc<64>(p, cpt, tab_lds, pairwise, per_chain, state_global, blocks, threads, lds_bytes, s);
+}
+#else
+hipError_t launch_sweep_card16(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, bool per_chain, bool state_global,
+                               uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t s);
+hipError_t launch_sweep_card64(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, bool per_chain, bool state_global,
+                               uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t s);
+
 hipError_t launch_sweep(const SweepParams &p, int max_card, bool cpt, bool tab_lds, bool pairwise, bool per_chain, bool state_global,
                         uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t s) {
-    hipError_t e = hipSuccess;
-    GR_DISPATCH_MAXC(max_card, {
-        if (state_global) // state in global memory: tables from global memory too; no strict mode, no draw log
-            e = (p.log || per_chain || tab_lds) ? hipErrorInvalidValue
-                : cpt ? launch_sweep_t<MC, true, false, false, false, false, true>(p, blocks, threads, lds_bytes, s)
-                : pairwise ? launch_sweep_t<MC, false, false, true, false, false, true>(p, blocks, threads, lds_bytes, s)
-                           : launch_sweep_t<MC, false, false, false, false, false, true>(p, blocks, threads, lds_bytes, s);
-        else if (p.log) e = (per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, false, true>(p, blocks, threads, lds_bytes, s);
-        else if (per_chain) e = tab_lds ? launch_sweep_t<MC, false, true, false, true>(p, blocks, threads, lds_bytes, s)
-                                   : launch_sweep_t<MC, false, false, false, true>(p, blocks, threads, lds_bytes, s);
-        else if (cpt) e = tab_lds ? launch_sweep_t<MC, true, true, false>(p, blocks, threads, lds_bytes, s)
-                             : launch_sweep_t<MC, true, false, false>(p, blocks, threads, lds_bytes, s);
-        else if (pairwise) e = tab_lds ? launch_sweep_t<MC, false, true, true>(p, blocks, threads, lds_bytes, s)
-                                       : launch_sweep_t<MC, false, false, true>(p, blocks, threads, lds_bytes, s);
-        else e = tab_lds ? launch_sweep_t<MC, false, true, false>(p, blocks, threads, lds_bytes, s)
-                         : launch_sweep_t<MC, false, false, false>(p, blocks, threads, lds_bytes, s);
-    });
-    return e;
+    if (max_card <= 2) return launch_sweep_mc<2>(p, cpt, tab_lds, pairwise, per_chain, state_global, blocks, threads, lds_bytes, s);
+    if (max_card <= 4) return launch_sweep_mc<4>(p, cpt, tab_lds, pairwise, per_chain, state_global, blocks, threads, lds_bytes, s);
+    if (max_card <= 16) return launch_sweep_card16(p, max_card, cpt, tab_lds, pairwise, per_chain, state_global, blocks, threads, lds_bytes, s);
+    return launch_sweep_card64(p, max_card, cpt, tab_lds, pairwise, per_chain, state_global, blocks, threads, lds_bytes, s);
 }
 
 hipError_t launch_init_state(unsigned char *state, const int32_t *card, const int32_t *fixed, uint32_t n_vars, uint32_t pitch,
@@ -920,5 +952,6 @@ hipError_t launch_collapse(const CollapseArgs &a, uint32_t blocks, hipStream_t s
     hipLaunchKernelGGL(k_collapse, dim3(blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
+#endif // GR_KSWEEP_PART
 
 } // namespace gr
