@@ -452,6 +452,8 @@ def _ring_model(n, deg, cards, seed):
     ("grid3x3", 7, 192, g.GR_FLAG_CHAIN_PER_LANE, 2),
     ("grid3x3", 6, 128, g.GR_FLAG_DIRECT, 0),
     ("Grids_11.uai", 2, 64, 0, 3),
+    ("Grids_11.uai", 40, 64, 0, 3),     # a window of ~5 500 steps: the ring halves are rebuilt by several blocks per group (window segments)
+    ("ring18_deg6_card4", 160, 64, 0, 8),  # the same (~4 500 steps) with one logged count per value
     ("mixed", 6, 128, 0, 1),            # cards 2, 3, 4: one logged count per value (memoised generic kernel)
     ("mixed_evidence", 5, 64, g.GR_FLAG_DIRECT, 0),
 ])
