@@ -452,6 +452,8 @@ def _ring_model(n, deg, cards, seed):
     ("grid3x3", 7, 192, g.GR_FLAG_CHAIN_PER_LANE, 2),
     ("grid3x3", 6, 128, g.GR_FLAG_DIRECT, 0),
     ("Grids_11.uai", 2, 64, 0, 3),
+    ("Grids_11.uai@form6", 3, 128, 0, 3),  # logged window with the records prefetched from global memory (two register sets)
+    ("grid3x3@form6", 6, 192, 0, 3),
     ("Grids_11.uai", 40, 64, 0, 3),     # a window of ~5 500 steps: the ring halves are rebuilt by several blocks per group (window segments)
     ("ring18_deg6_card4", 160, 64, 0, 8),  # the same (~4 500 steps) with one logged count per value
     ("mixed", 6, 128, 0, 1),            # cards 2, 3, 4: one logged count per value (memoised generic kernel)
@@ -463,9 +465,12 @@ def test_advance_chain_stop_rule_and_rings_vs_emulator(res_dir, model, cw, chain
     from tests.test_gpu_parity import _thresholds_from_device, _gm
     rings = {"ring24_deg6": lambda: _ring_model(24, 6, [2], 1), "ring20_deg10_binary": lambda: _ring_model(20, 10, [2], 2),
              "ring18_deg6_card4": lambda: _ring_model(18, 6, [2, 3, 4], 3), "ring12_deg3_card16": lambda: _ring_model(12, 3, [9, 11, 16, 16], 4)}
+    form = 0
+    if model.endswith("@form6"):  # the 4-lane form with its records read from global memory (the headline configuration's record mode)
+        model, form = model[:-6], 6
     pm = uai_py.load(res_dir, model) if model.endswith(".uai") else rings[model]() if model in rings else exact_chain.tiny_models()[model]
     n = len(pm.card)
-    s = g.HIPChains(_gm(pm), chains, seed=77, flags=flags)
+    s = g.HIPChains(_gm(pm), chains, seed=77, flags=flags, fast_form=form)
     assert s.info()["path"] == path
     if model == "ring24_deg6":
         assert s.info()["tables_in_lds"] == 0
