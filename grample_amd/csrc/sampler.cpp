@@ -491,9 +491,13 @@ void gr_sampler::rebuild() {
     pairwise = true;
     for (const auto &im : image) pairwise = pairwise && im.pairwise;
     std::vector<float> views;
+    // Only the groups that run are built: the groups an adaptive run has not activated yet are clones of the base model that no
+    // kernel touches (every launch covers the active prefix), and an activation rebuilds anyway -- with 2 of 128 groups
+    // active a full build was 64 times the work needed.
+    const uint32_t n_build = o.n_variants > 1 ? n_active : o.n_variants;
     h_variants.assign(o.n_variants, VariantDesc{});
     uint32_t cpt_total = 0;
-    for (uint32_t g = 0; g < o.n_variants; ++g) {
+    for (uint32_t g = 0; g < n_build; ++g) {
         const VariantImage &im = image[g];
         VariantDesc &vd = h_variants[g];
         vd.prog_base = (uint32_t)progs.size();
@@ -536,14 +540,14 @@ void gr_sampler::rebuild() {
     d_cpt.alloc(cpt_total + 4);
     hip_check(hipMemsetAsync(d_cpt.p, 0, (cpt_total + 4) * sizeof(uint32_t), stream), "hipMemset");
     if (cpt)
-        for (uint32_t g = 0; g < o.n_variants; ++g)
+        for (uint32_t g = 0; g < n_build; ++g)
             hip_check(launch_build_cpt(h_variants[g], d_progs.p, d_prog_off.p, d_views.p, d_cprogs.p, d_cprog_off.p, d_cpt.p,
                                        d_card.p, d_fixed.p, (uint32_t)n_vars, std::max(1u, image[g].max_cfg), max_card, stream),
                       "k_build_cpt");
     if (fast) {
         std::vector<uint32_t> recs;
         uint32_t rec_count = 0;
-        for (uint32_t g = 0; g < o.n_variants; ++g) {
+        for (uint32_t g = 0; g < n_build; ++g) {
             const VariantImage &im = image[g];
             h_variants[g].rec_base = rec_count;
             rec_count += (uint32_t)im.free_vars.size();
@@ -569,7 +573,7 @@ void gr_sampler::rebuild() {
         d_recs.upload(recs, stream, stage);
         if (par) { // same records for the step-parallel layout: 80-byte state rows, block-level histogram
             std::vector<uint32_t> rp;
-            for (uint32_t g = 0; g < o.n_variants; ++g) {
+            for (uint32_t g = 0; g < n_build; ++g) {
                 const VariantImage &im = image[g];
                 uint32_t rank = 0;
                 for (uint32_t v : im.free_vars) {
@@ -604,7 +608,7 @@ void gr_sampler::rebuild() {
         // step headers + factor entries of the direct 4-lane form, from the generic programs (compiled_model.hpp)
         std::vector<uint32_t> hdr, ent;
         uint32_t rec_count = 0;
-        for (uint32_t g = 0; g < o.n_variants; ++g) {
+        for (uint32_t g = 0; g < n_build; ++g) {
             const VariantImage &im = image[g];
             h_variants[g].rec_base = rec_count;
             rec_count += (uint32_t)im.free_vars.size();
@@ -1462,6 +1466,7 @@ GR_VISIBLE int gr_set_active_groups(gr_sampler *s, uint32_t n_active) {
         if (s->started) throw Error(GR_E_STATE, "gr_set_active_groups must precede burn-in / advance");
         if (n_active < 1 || n_active > s->o.n_variants) throw Error(GR_E_INVALID, "n_active out of range");
         s->n_active = n_active;
+        s->dirty = true; // the device pools hold the active groups only
     });
 }
 GR_VISIBLE int gr_active_groups(gr_sampler *s) { return s ? (int)s->n_active : fail(GR_E_INVALID, "null sampler"); }
@@ -1790,6 +1795,7 @@ GR_VISIBLE int gr_conditional(gr_sampler *s, uint32_t variant, int32_t v, const 
     return guarded([&] {
         if (!s || !state || !probs_out) throw Error(GR_E_INVALID, "null argument");
         if (variant >= s->o.n_variants || v < 0 || v >= s->n_vars) throw Error(GR_E_INVALID, "bad variant / variable");
+        if (s->o.n_variants > 1 && variant >= s->n_active) throw Error(GR_E_STATE, "chain group is not active (its device tables are built when it is activated)");
         const Variable &var = s->vmodel[variant].Vars[v];
         if (var.FixedVal >= 0) throw Error(GR_E_INVALID, "Selected sample variable " + var.Name + " which has FixedVal=" + std::to_string(var.FixedVal));
         if (var.Collapsed) throw Error(GR_E_INVALID, "variable is collapsed");
