@@ -79,6 +79,7 @@ SIGNATURES = {
     "gr_merge": (C.c_int, [C.POINTER(vp), C.c_int, pd, pi32]),
     "gr_merge_local": (C.c_int, [vp, pd, pi32, pd]),
     "gr_allreduce_counts": (C.c_int, [C.POINTER(vp), C.c_int, pu64]),
+    "gr_rccl_calls": (u64, []),
     "gr_state": (C.c_int, [vp, u32, pi32]),
     "gr_set_state": (C.c_int, [vp, u32, pi32]),
     "gr_conditional": (C.c_int, [vp, u32, i32, pi32, pd]),

@@ -388,6 +388,11 @@ def MergeChains(samplers):
     return split(out, samplers[0].cards), coll
 
 
+def rccl_calls():
+    """ncclAllReduce calls completed inside gr_allreduce_counts by this process (0 = RCCL never ran)."""
+    return int(_lib.lib().gr_rccl_calls())
+
+
 def allreduce_counts(samplers):
     L = _lib.lib()
     arr = (C.c_void_p * len(samplers))(*[s.ptr for s in samplers])

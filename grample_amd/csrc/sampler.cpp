@@ -5,6 +5,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -26,6 +28,7 @@ using namespace gr;
 namespace {
 
 thread_local std::string g_err;
+std::atomic<uint64_t> g_rccl_calls{0}; // ncclAllReduce calls completed by gr_allreduce_counts (gr_rccl_calls)
 
 int fail(int code, const std::string &msg) {
     g_err = msg;
@@ -1417,7 +1420,11 @@ GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t 
             if (!samplers[i] || (size_t)samplers[i]->o.n_variants * samplers[i]->H != cnt) throw Error(GR_E_INVALID, "samplers differ in shape");
             devs[i] = samplers[i]->o.device;
         }
-        if (n > 1) {
+        // One sampler needs no exchange: its counts are the total.  GR_ALLREDUCE_FORCE_RCCL=1 (read once) takes the RCCL branch
+        // all the same -- ncclCommInitAll over one device is legal -- so that the collective of the path can be executed and
+        // checked on a one-GPU box (tests/test_gpu_dist.py).
+        static const bool force_rccl = [] { const char *e = getenv("GR_ALLREDUCE_FORCE_RCCL"); return e && e[0] == '1'; }();
+        if (n > 1 || force_rccl) {
             // RCCL is bound lazily: a host process that brings its own RCCL (e.g. PyTorch) never sees a second copy
             static void *h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
             if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -1428,6 +1435,9 @@ GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t 
             auto pGroupEnd = reinterpret_cast<ncclResult_t (*)()>(dlsym(h, "ncclGroupEnd"));
             auto pDestroy = reinterpret_cast<ncclResult_t (*)(ncclComm_t)>(dlsym(h, "ncclCommDestroy"));
             if (!pInitAll || !pAllReduce || !pGroupStart || !pGroupEnd || !pDestroy) throw Error(GR_E_NO_DEVICE, "librccl.so lacks the expected symbols");
+            for (int i = 0; i < n; ++i)
+                for (int k = 0; k < i; ++k)
+                    if (devs[i] == devs[k]) throw Error(GR_E_INVALID, "gr_allreduce_counts: one sampler per device (two samplers share device " + std::to_string(devs[i]) + ")");
             // out of place, into a scratch buffer per device: every sampler's own counts stay what its chains sampled, so
             // gr_merge / gr_counts / further gr_advance calls after the reduction see unchanged data
             for (int i = 0; i < n; ++i) { samplers[i]->use(); samplers[i]->d_reduced.alloc(cnt); }
@@ -1447,6 +1457,7 @@ GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t 
             if (re != ncclSuccess) r = re;
             for (int i = 0; i < n; ++i) { samplers[i]->use(); samplers[i]->sync(); }
             if (r != ncclSuccess) throw Error(GR_E_NO_DEVICE, "ncclAllReduce failed");
+            g_rccl_calls.fetch_add(1, std::memory_order_relaxed);
             if (out) {
                 gr_sampler *s0 = samplers[0];
                 s0->use();
@@ -1458,6 +1469,7 @@ GR_VISIBLE int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t 
     });
 }
 
+GR_VISIBLE uint64_t gr_rccl_calls(void) { return g_rccl_calls.load(std::memory_order_relaxed); }
 
 // ============================================================ adaptive (N2)
 GR_VISIBLE int gr_set_active_groups(gr_sampler *s, uint32_t n_active) {

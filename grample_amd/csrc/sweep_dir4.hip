@@ -215,7 +215,13 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
                         lds_u32d_t *hp = lds_at_d(h.y);
                         __hip_atomic_fetch_add(hp, 16u - (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         __hip_atomic_fetch_add(hp + 1, (uint32_t)s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (LOG && logrow) logrow[sidx] = (unsigned char)s1;
+                        if (LOG && logrow) {
+                            // one byte per step (the ones) when every selectable variable is binary; a model with max Card 2
+                            // that has a selectable Card-1 variable is logged with one count per value like the generic kernel
+                            // does (gr_advance_chain: log_vals = max Card), or k_ring_halves would read a pitch this kernel did not write
+                            if (p.log_vals == 1) logrow[sidx] = (unsigned char)s1;
+                            else { logrow[(size_t)sidx * p.log_vals] = (unsigned char)(16 - s1); logrow[(size_t)sidx * p.log_vals + 1] = (unsigned char)s1; }
+                        }
                     }
                 } else {
                     if (runs) __hip_atomic_fetch_add(lds_at_d(h.y + 4u * val), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

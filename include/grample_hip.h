@@ -203,6 +203,11 @@ int gr_merge_local(gr_sampler *s, double *out_sum /*[total_card]*/, int32_t *out
  * counts stay what its chains sampled, so gr_merge, gr_counts and further
  * gr_advance calls are unaffected.  out may be NULL. */
 int gr_allreduce_counts(gr_sampler *const *samplers, int n, uint64_t *out /*[n_variants*total_card]*/);
+/* With n == 1 there is nothing to exchange and the call returns the sampler's own counts without touching RCCL;
+ * the environment variable GR_ALLREDUCE_FORCE_RCCL=1 (read once per process) makes it run the collective all the
+ * same (a one-device communicator), which is how the RCCL branch is exercised on a one-GPU box.
+ * gr_rccl_calls: ncclAllReduce calls this process has completed inside gr_allreduce_counts (0 = RCCL never ran). */
+uint64_t gr_rccl_calls(void);
 
 /* Chain.LastSample of one chain (chain.go:19) */
 int gr_state(gr_sampler *s, uint32_t chain, int32_t *out /*[n_vars]*/);

@@ -1,23 +1,29 @@
 #!/bin/bash
-# Round-2 measurement pass on the GPU box: bench line, rocprofv3 kernel stats of the same command, and the PMC passes
-# (separate runs, --pmc with --kernel-trace only) that bench.py's `traffic` / `limiter` fields come from.
-# Everything lands under gpurun_out/r02/; scripts/store_profiles.py copies the summaries into profiles/.
+# Measurement pass on the GPU box (gpurun -- 'bash scripts/collect_profiles.sh r03'): bench line, rocprofv3 kernel stats of the
+# same command, and the PMC passes (separate runs, --pmc with --kernel-trace only) that bench.py's roofline object is built from.
+# Everything lands under gpurun_out/<tag>/; scripts/store_profiles.py <tag> copies the summaries into profiles/ and writes
+# profiles/roofline_inputs.json.  QUICK=1 skips the long side measurements (all models, seed noise, ...).
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/$TAG
 mkdir -p $O
 rm -f $O/seed_noise.txt
-python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || exit 1
-echo "bench done"; tail -c 600 $O/bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
+python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
+echo "bench done"; head -c 400 $O/bench.json; echo
+B="python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- $B > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
 echo "stats done"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err || exit 1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err || exit 1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o run -- $B > /dev/null 2> $O/pmc_fetch.err || exit 1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o run -- $B > /dev/null 2> $O/pmc_write.err || exit 1
 echo "hbm pmc done"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_sqA -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_sqA.err || exit 1
-rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH --kernel-trace --output-format csv -d $O/pmc_sqB -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_sqB.err || exit 1
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_gui -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_gui.err || exit 1
+B2="python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/pmc_sqA -o run -- $B2 > /dev/null 2> $O/pmc_sqA.err || exit 1
+rocprofv3 --pmc SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH --kernel-trace --output-format csv -d $O/pmc_sqB -o run -- $B2 > /dev/null 2> $O/pmc_sqB.err || exit 1
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_gui -o run -- $B2 > /dev/null 2> $O/pmc_gui.err || exit 1
 echo "sq pmc done"
+python3 $R/scripts/isa_mix.py --json > $O/isa_mix.json 2> $O/isa_mix.err
+[ -n "$QUICK" ] && { echo "quick pass done"; exit 0; }
 python3 $R/scripts/bench_configs.py > $O/configs.jsonl 2> $O/configs.err || exit 1
 echo "configs done"
 python3 $R/scripts/dev_time.py > $O/dev_time.txt 2>&1

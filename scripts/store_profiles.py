@@ -10,7 +10,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 G, P = os.path.join(ROOT, "gpurun_out", TAG), os.path.join(ROOT, "profiles")
 KERN = "k_sweep_par4<4, true, 1, 2, 0>"
 UPD_PER_LAUNCH = 50000 * 65536  # a bench step (100 000 updates per chain) = 2 launches
@@ -54,6 +54,52 @@ def main():
         gr_ = rows("gui", "GRBM_GUI_ACTIVE", KERN)
         if gr_:
             sclk = sum(float(r["Counter_Value"]) / 8.0 / (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in gr_) / len(gr_)
+    # ---- profiles/roofline_inputs.json: what bench.py's roofline object is computed from
+    import hashlib
+    import subprocess
+    UPD2 = 100000.0 * 65536.0  # one bench step = two sweep launches
+    def per64_of(tag, ctr):
+        v = vals(tag, ctr, KERN)
+        return sum(v[-2:]) / (UPD2 / 64.0)
+    valu64, lds64, salu64 = per64_of("sqA", "SQ_INSTS_VALU"), per64_of("sqA", "SQ_INSTS_LDS"), per64_of("sqA", "SQ_INSTS_SALU")
+    vmem64, br64 = per64_of("sqA", "SQ_INSTS_VMEM_RD"), per64_of("sqB", "SQ_INSTS_BRANCH")
+    mix_path = os.path.join(G, "isa_mix.json")
+    mix = json.load(open(mix_path)) if os.path.exists(mix_path) and os.path.getsize(mix_path) else \
+        json.loads(subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "isa_mix.py"), "--json"], check=True, capture_output=True, text=True).stdout)
+    json.dump(mix, open(os.path.join(P, f"{TAG}_isa_mix.json"), "w"), indent=1)
+
+    def priced(cls, dyn_per64):
+        """dynamic instruction count x static price: the loop's shortest path (a wavefront iteration = 256 updates without dependency
+        levels) at its own mean cost, the instructions beyond it (level passes) at the mean cost of the rest of the loop"""
+        full, short = mix["classes"][cls], mix["classes_short_path"][cls]
+        unroll = 2.0  # the loop body holds two wavefront iterations (register sets A / B)
+        n_short = short["instructions"] / unroll / 4.0   # per 64 updates
+        c_short = short["port_cycles"] / unroll / 4.0
+        rest_n = full["instructions"] - short["instructions"]
+        rest_mean = (full["port_cycles"] - short["port_cycles"]) / rest_n if rest_n else short["mean_cycles"]
+        extra = max(dyn_per64 - n_short, 0.0)
+        cyc = (c_short if dyn_per64 >= n_short else dyn_per64 * short["mean_cycles"]) + extra * rest_mean
+        return cyc, cyc / dyn_per64
+    vc, vmean = priced("valu", valu64)
+    lc, lmean = priced("lds", lds64)
+    h = hashlib.sha256()
+    cs = os.path.join(ROOT, "grample_amd", "csrc")
+    for f_ in sorted(os.listdir(cs)):
+        if f_.endswith((".hip", ".h", ".hpp", ".cpp")):
+            h.update(f_.encode()); h.update(open(os.path.join(cs, f_), "rb").read())
+    ri = {"round": int(TAG[1:]), "sources_sha": h.hexdigest()[:16],
+          "kernel": f"gr::{KERN}", "command": "python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline under rocprofv3 --pmc (scripts/collect_profiles.sh)",
+          "updates_per_launch": UPD_PER_LAUNCH, "hbm_bytes_per_launch": int(2 * fm * 1024 + wm * 1024),
+          "sclk_ghz_measured": round(sclk, 3) if sclk else None,
+          "valu_inst_per_64_updates": round(valu64, 3), "lds_inst_per_64_updates": round(lds64, 3), "salu_inst_per_64_updates": round(salu64, 3),
+          "vmem_inst_per_64_updates": round(vmem64, 3), "branch_inst_per_64_updates": round(br64, 3),
+          "valu_mean_cycles": round(vmean, 3), "lds_mean_cycles": round(lmean, 3),
+          "valu_port_cycles_per_update": round(vc / 64.0, 4), "lds_port_cycles_per_update": round(lc / 64.0, 4),
+          "avg_launch_ns": int(float(sw["AverageNs"])),
+          "pricing": "dynamic SQ counts (profiles/%s_pmc_sq*.csv) x static mix of the loop (profiles/%s_isa_mix.json, scripts/isa_mix.py) x measured issue costs "
+                     "(profiles/r03_issue_rate_ubench.txt, 4 wavefronts per SIMD)" % (TAG, TAG)}
+    json.dump(ri, open(os.path.join(P, "roofline_inputs.json"), "w"), indent=2)
+    print("roofline_inputs:", ri["valu_inst_per_64_updates"], ri["valu_mean_cycles"], ri["valu_port_cycles_per_update"], ri["lds_port_cycles_per_update"], ri["sclk_ghz_measured"])
     d = {
         "round": int(TAG[1:]),
         "sclk_ghz_measured": round(sclk, 3) if sclk else None,

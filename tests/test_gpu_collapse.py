@@ -428,12 +428,14 @@ def _expected_rings(em, n, cw, groups):
     return batches * 2 * n, made, first, second
 
 
-def _ring_model(n, deg, cards, seed):
+def _ring_model(n, deg, cards, seed, force=None):
     """n variables on a ring, every variable sharing a pairwise factor with its next `deg` neighbours (blanket 2 * deg):
-    large enough blankets push a small model off the LDS-table / memoised paths"""
+    large enough blankets push a small model off the LDS-table / memoised paths.  force = {variable: Card} overrides."""
     from types import SimpleNamespace
     rng = np.random.default_rng(seed)
     card = [int(rng.choice(cards)) for _ in range(n)]
+    for v, c in (force or {}).items():
+        card[v] = c
     scopes, tables = [], []
     for v in range(n):
         scopes.append([v]); tables.append(np.exp(rng.uniform(-1, 1, card[v])))
@@ -447,6 +449,8 @@ def _ring_model(n, deg, cards, seed):
     ("ring24_deg6", 4, 128, 0, 3),      # 24 x 2^12 threshold words: the 4-lane form with tables from global memory, logged
     ("ring20_deg10_binary", 4, 128, 0, 8),  # blankets of 20 binary variables: not memoisable -> step-parallel direct kernel, logged
     ("ring18_deg6_card4", 3, 64, 0, 8),     # cards 2..4, blankets of 12: step-parallel direct kernel, one logged count per value
+    ("ring20_deg10_card1", 4, 128, 0, 8),   # max Card 2 with ONE selectable Card-1 variable: not "all binary", so the log holds one count
+                                            # per value (2 bytes per step) -- also from the Card <= 2 instantiation of the step-parallel kernel
     ("ring12_deg3_card16", 3, 128, 0, 6),   # cards 9..16, pairwise, not memoisable: value-parallel kernel, 16 logged counts per step
     ("grid3x3", 6, 192, 0, 3),
     ("grid3x3", 7, 192, g.GR_FLAG_CHAIN_PER_LANE, 2),
@@ -464,7 +468,8 @@ def test_advance_chain_stop_rule_and_rings_vs_emulator(res_dir, model, cw, chain
     from tests.emulator import Emulator
     from tests.test_gpu_parity import _thresholds_from_device, _gm
     rings = {"ring24_deg6": lambda: _ring_model(24, 6, [2], 1), "ring20_deg10_binary": lambda: _ring_model(20, 10, [2], 2),
-             "ring18_deg6_card4": lambda: _ring_model(18, 6, [2, 3, 4], 3), "ring12_deg3_card16": lambda: _ring_model(12, 3, [9, 11, 16, 16], 4)}
+             "ring18_deg6_card4": lambda: _ring_model(18, 6, [2, 3, 4], 3),
+             "ring20_deg10_card1": lambda: _ring_model(20, 10, [2], 6, force={7: 1}), "ring12_deg3_card16": lambda: _ring_model(12, 3, [9, 11, 16, 16], 4)}
     form = 0
     if model.endswith("@form6"):  # the 4-lane form with its records read from global memory (the headline configuration's record mode)
         model, form = model[:-6], 6
