@@ -799,6 +799,23 @@ static orc_chain *chain_new(orc_model *m, orc_simple *s, orc_collapsed *g, int c
 ORC_API orc_chain *orc_chain_new_simple(orc_model *m, orc_simple *s, int cw, int64_t burn_in) { return chain_new(m, s, NULL, cw, burn_in); }
 ORC_API orc_chain *orc_chain_new_collapsed(orc_model *m, orc_collapsed *g, int cw, int64_t burn_in) { return chain_new(m, NULL, g, cw, burn_in); }
 ORC_API orc_chain *orc_chain_new_nosampler(orc_model *m) { return chain_new(m, NULL, NULL, 0, 0); } /* chain_test.go:32 */
+/* Test hooks (tests/test_gpu_adaptive.py): a chain without a sampler whose ChainHistory rings hold ring_size values while its
+ * ConvergenceWindow is cw -- one such chain stands for a 64-chain group of the GPU path, its rings holding the values of all
+ * the group's chains (the distance measures of ChainDist normalise their histograms, chain.go:253-290) -- and the ring
+ * write of oneSample alone (chain.go:238-241). */
+ORC_API orc_chain *orc_chain_new_history(orc_model *m, int cw, int ring_size) {
+    orc_chain *c = chain_new(m, NULL, NULL, 0, 0);
+    if (!c) return NULL;
+    c->cw = cw;
+    for (int i = 0; i < m->nvars; i++) { orc_ring_free(c->history[i]); c->history[i] = orc_ring_new(ring_size); }
+    return c;
+}
+ORC_API int orc_chain_history_add(orc_chain *c, int var, int value) {
+    if (var < 0 || var >= c->target->nvars || value < 0 || value >= c->target->vars[var].card) return orc_fail("history add out of range");
+    orc_ring_add(c->history[var], value);
+    c->total_seen[var]++;
+    return 0;
+}
 ORC_API void orc_chain_free(orc_chain *c) {
     if (!c) return;
     if (c->history) for (int i = 0; i < c->target->nvars; i++) orc_ring_free(c->history[i]);

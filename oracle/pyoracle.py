@@ -93,6 +93,8 @@ def lib():
     sig("orc_chain_new_collapsed", vp, vp, vp, i32, i64)
     sig("orc_chain_new_nosampler", vp, vp)
     sig("orc_chain_free", None, vp)
+    sig("orc_chain_new_history", vp, vp, i32, i32)
+    sig("orc_chain_history_add", i32, vp, i32, i32)
     sig("orc_chain_total_samples", i64, vp)
     sig("orc_chain_get_last", None, vp, pi)
     sig("orc_chain_advance", i32, vp)
