@@ -147,9 +147,15 @@ def _run_oracle(oracle, base, pm, sol, seed, rounds, add, cw, burn):
     return out
 
 
-def test_adaptive_run_matches_oracle_ensemble(res_dir, oracle):
-    """Segmentation_11 (228 variables, 227 eligible), 2 -> 14 chains in 5 rounds, cw 50, burn-in 2 000, 24 seeds a side."""
-    name, rounds, add, cw, burn, S = "Segmentation_11.uai", 5, 3, 50, 2000, 24
+@pytest.mark.parametrize("rounds,add,cw,S,min_keep,rises", [
+    (5, 3, 50, 24, 100, False),   # script/experiment's shape: 2 -> 14 chains; 12 collapsed variables of 228: sampling still improves faster than the
+                                  # collapsed variables' local marginals cost -- MeanHellinger falls a little, on both sides alike
+    (4, 20, 20, 16, 20, True),    # 2 -> 62 chains: 60 collapsed variables -- MeanHellinger RISES, on both sides alike (what profiles/r02_adaptive_experiment.txt
+                                  # shows between 34 and 128 groups)
+])
+def test_adaptive_run_matches_oracle_ensemble(res_dir, oracle, rounds, add, cw, S, min_keep, rises):
+    """Segmentation_11 (228 variables, 227 eligible), burn-in 2 000, S seeds a side."""
+    name, burn = "Segmentation_11.uai", 2000
     pm = uai_py.load(res_dir, name)
     sol = uai_py.load_mar(res_dir, name)
     gm = g.Model.NewModelFromFile(os.path.join(res_dir, name))
@@ -165,20 +171,26 @@ def test_adaptive_run_matches_oracle_ensemble(res_dir, oracle):
             assert len(set(picked)) == len(picked) == add * (rounds - 1)   # never the same variable twice (adaptive.go:84: !Collapsed)
     # window lengths: a GPU group of 64 chains plays one reference chain -> counted updates per chain are the same on average
     for r in range(rounds):
-        gs = np.mean([run[r]["samples"] for run in G]) / 64.0
-        os_ = np.mean([run[r]["samples"] for run in Or])
-        assert abs(gs - os_) / os_ < 0.05, (r, gs, os_)
+        ga, oa = np.array([run[r]["samples"] for run in G]) / 64.0, np.array([run[r]["samples"] for run in Or], dtype=float)
+        gs, os_ = ga.mean(), oa.mean()
+        se = np.sqrt(ga.var(ddof=1) / S + oa.var(ddof=1) / S)
+        assert abs(gs - os_) < max(0.05 * os_, 4.0 * se), (r, gs, os_, se)
     # (i) the merged marginals of the variables nobody collapsed: two-sample z over the seeds, at the last round and at round 0
     ever = np.zeros(n, dtype=bool)
     for runs in (G, Or):
         for run in runs:
             ever |= run[-1]["coll"].astype(bool)
     keep = np.where(~ever)[0]
-    assert len(keep) > 100
+    assert len(keep) > min_keep
     for r in (0, rounds - 1):
         pg = np.array([[run[r]["merged"][v][1] for v in keep] for run in G])
         po = np.array([[run[r]["merged"][v][1] for v in keep] for run in Or])
-        se = np.sqrt(pg.var(axis=0, ddof=1) / S + po.var(axis=0, ddof=1) / S)
+        # Segmentation_11 is multi-modal: a chain can sit in a minority mode for a whole window, so a run's estimate is far from
+        # normal and S runs of TWO reference chains can miss a mode that 128 device chains per run reveal (their variance estimate
+        # is then far too small).  Under the hypothesis tested -- the same per-chain law -- a reference run's variance is 64 x a
+        # device run's (64 chains behind each group): the oracle's variance estimate is floored by that
+        vg, vo = pg.var(axis=0, ddof=1), po.var(axis=0, ddof=1)
+        se = np.sqrt(vg / S + np.maximum(vo, 64.0 * vg) / S)
         z = (pg.mean(axis=0) - po.mean(axis=0)) / np.maximum(se, 1e-3)
         assert np.max(np.abs(z)) <= 5.5 and np.mean(z ** 2) <= 2.0, (r, np.max(np.abs(z)), np.mean(z ** 2))
     # ... and their error against the exact marginals, seed-averaged estimate (the sampling noise of ONE run differs by design:
@@ -207,7 +219,7 @@ def test_adaptive_run_matches_oracle_ensemble(res_dir, oracle):
     assert mh_g0 <= mh_o0 + 0.005, (mh_g0, mh_o0)
     exp_rise = (add * (rounds - 1) / (n - 0.0)) * 0.15  # 12 of 228 variables moving from ~0.2 to ~0.4
     for rise, base0, tag in ((rise_g, mh_g0, "gpu"), (rise_o, mh_o0, "oracle")):
-        assert rise > -0.02, (tag, rise)
+        assert (rise > 0.0) if rises else (-0.04 < rise < 0.005), (tag, rise)
     assert abs(rise_g - rise_o) < 0.02, (rise_g, rise_o, exp_rise)
     # Adapt prefers the same variables: mean ChainConvergence score per variable over the seeds (first Adapt, same ensemble shape)
     cg = np.nanmean([run[0]["conv"] for run in G], axis=0)
@@ -221,6 +233,11 @@ def test_adaptive_run_matches_oracle_ensemble(res_dir, oracle):
     pick_g = [v for run in G for v in run[0]["picks"]]
     pick_o = [v for run in Or for v in run[0]["picks"]]
     assert np.mean([v in lowq(co) for v in pick_g]) > 0.6 and np.mean([v in lowq(cg) for v in pick_o]) > 0.6
+    print(f"\nadaptive GPU vs oracle ({S} seeds a side): MeanHellinger per round gpu "
+          + " ".join(f"{np.mean([run[r]['mh'] for run in G]):.4f}" for r in range(rounds)) + " | oracle "
+          + " ".join(f"{np.mean([run[r]['mh'] for run in Or]):.4f}" for r in range(rounds))
+          + f" | rise gpu {rise_g:+.4f} oracle {rise_o:+.4f} | score rank correlation {rho:.3f} | picks in the other side's low third: "
+          f"gpu {np.mean([v in lowq(co) for v in pick_g]):.2f} oracle {np.mean([v in lowq(cg) for v in pick_o]):.2f}")
 
 
 def test_collapsed_variables_carry_the_oracles_local_marginal(res_dir, oracle):
