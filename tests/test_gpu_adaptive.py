@@ -277,3 +277,62 @@ def test_collapsed_variables_carry_the_oracles_local_marginal(res_dir, oracle):
     # the run's own MeanHellinger = the blend of the two populations
     es = g.NewErrorSuite(pm.card, sol, merged)
     assert es["MeanHellinger"] == pytest.approx((np.sum(h_coll) + np.sum(h_samp)) / n, rel=1e-9)
+
+
+def test_experiment_trace_file(res_dir, tmp_path):
+    """N3: tools/grample_hip_sample --experiment --trace FILE writes what cmd/root.go:455-458, 520-533, 586-600 write: the header,
+    one line per advance round -- RunSecs, MaxHell, NegLogMaxHell, MaxJS, NegLogMaxJS, CollapseCount -- the line after the final merge
+    and the FINAL STATUS block.  The same run replayed through the C ABI (same seed, groups, ConvergenceWindow; device results are
+    deterministic) gives the same scores to the printed digits, and CollapseCount is the number of collapsed flags gr_merge returns."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "grample_hip_sample")
+    if not os.path.exists(exe):
+        pytest.skip("tools/grample_hip_sample not built")
+    name, K, cpg, cw, burn, R, AR, add, seed = "Segmentation_11.uai", 16, 64, 20, 2000, 6, 3, 4, 5
+    trace = tmp_path / "seg.trace"
+    cmd = [exe, "-m", os.path.join(res_dir, name), "-o", "-s", "adaptive", "-c", str(K * cpg), "-k", str(K), "-b", str(burn), "-w", str(cw), "-r", str(R),
+           "--adapt-rounds", str(AR), "-a", str(add), "-e", str(seed), "--experiment", "-t", str(trace), "-i", str(10 ** 12)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = trace.read_text().splitlines()
+    assert lines[0] == "// EXPERIMENT RESULTS"
+    assert lines[1] == "RunSecs, MaxHell, NegLogMaxHell, MaxJS, NegLogMaxJS, CollapseCount"
+    fin = lines.index("// FINAL STATUS")
+    rows = [[float(x) for x in ln.split(",")] for ln in lines[2:fin]]
+    assert len(rows) == R + 1 and all(len(r) == 6 for r in rows)  # one per round + the one after the final merge
+    for r in rows:
+        assert r[2] == pytest.approx(-np.log2(r[1]), abs=2e-5) and r[4] == pytest.approx(-np.log2(r[3]), abs=2e-5)
+    assert [r[0] for r in rows] == sorted(r[0] for r in rows)  # RunSecs
+    assert lines[fin + 1] == "FINAL ... M:mean(neg log), X:max(neg log)"
+    assert [ln.split("=>")[0].strip() for ln in lines[fin + 2:fin + 6]] == ["MeanAbsError", "MaxAbsError", "Hellinger", "JS Diverge"]
+    assert "// OPERATING PARAMS" in lines
+    # the replay
+    pm = uai_py.load(res_dir, name)
+    sol = uai_py.load_mar(res_dir, name)
+    s = g.HIPChains.NewGibbsCollapsed(g.Model.NewModelFromFile(os.path.join(res_dir, name)), K * cpg, K, seed=seed)
+    s.set_active_groups(2)
+    s.BurnIn(burn)
+    want = []
+    for r in range(R):
+        s.AdvanceChain(cw)
+        merged, coll = g.MergeChains([s])
+        es = g.NewErrorSuite(pm.card, sol, merged)
+        want.append((es["MaxHellinger"], es["MaxJSDiverge"], int(coll.sum())))
+        if r < AR:
+            s.Adapt(add)
+    merged, coll = g.MergeChains([s])
+    es = g.NewErrorSuite(pm.card, sol, merged)
+    want.append((es["MaxHellinger"], es["MaxJSDiverge"], int(coll.sum())))
+    assert [int(r[5]) for r in rows] == [w[2] for w in want] == [0, 4, 8, 12, 12, 12, 12]
+    for r, w in zip(rows, want):
+        assert r[1] == pytest.approx(w[0], abs=6e-9) and r[3] == pytest.approx(w[1], abs=6e-9)
+    # stdout: the reference's ADAPT lines and the collapsed variables behind the last CollapseCount
+    assert out.stdout.count("ADAPT: ") == AR and "STOPPING ADAPTATION" in out.stdout
+    cl = [ln for ln in out.stdout.splitlines() if ln.startswith("COLLAPSED VARS")][0]
+    assert sorted(int(x) for x in cl.split(":")[1].split()) == np.where(coll)[0].tolist()
+    mh = float(lines[fin + 4].split("M:")[1].split("(")[0])
+    assert mh == pytest.approx(es["MeanHellinger"], abs=1e-6)
+    # experiment mode without a trace file is refused like root.go:315-317
+    bad = subprocess.run([exe, "-m", os.path.join(res_dir, name), "-o", "--experiment"], capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0 and "requires a trace file" in bad.stderr

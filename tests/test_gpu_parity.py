@@ -646,7 +646,7 @@ def test_cpp_host_driver(res_dir):
                           "-r", "2", "-e", "42"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "DONE" in out.stdout
-    final = [ln for ln in out.stdout.splitlines() if ln.startswith("FINAL")][0]
+    final = [ln for ln in out.stdout.splitlines() if ln.startswith("FINAL MeanHellinger=")][0]
     mh = float(final.split("MeanHellinger=")[1].split()[0])
     s = g.HIPChains.NewGibbsSimple(g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai")), 4096, seed=42)
     s.BurnIn(2000); s.Advance(4000); s.Advance(4000)

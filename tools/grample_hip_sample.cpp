@@ -11,6 +11,13 @@
 //   -i MAXITERS: like the reference's --maxiters it bounds the TOTAL sample count over all chains (root.go:482-496: the loop
 //      ends once sampleCount > maxIters); a round advances every chain by ceil(MAXITERS / (ROUNDS * CHAINS)) updates
 //   -w CWIN: every round is one Chain.AdvanceChain with ConvergenceWindow CWIN (chain.go:180-218) instead
+//   --experiment -t TRACE: experiment mode (root.go:455-458, 520-533, 586-600): the trace file gets the header and one line per advance
+//      round -- RunSecs, MaxHell, NegLogMaxHell, MaxJS, NegLogMaxJS, CollapseCount -- a last line after the final merge and the FINAL
+//      STATUS block; needs -o (the scores come from the .MAR solution) and a trace file (root.go:315-317)
+//   -x MAXSECS: wall-clock bound of the main loop (root.go:464, 483-485; 0 = none, the rounds / maxiters bounds remain); in adaptive
+//      mode Adapt runs only during the first MAXSECS / 2 seconds (root.go:469, 542-547)
+//   -a CHAINADDS: chain groups added per Adapt (root.go:202; must be 1 unless the sampler is adaptive, root.go:440-442)
+//   --adapt-rounds K (not a reference flag): adapt after each of the first K rounds instead of by wall time -- reproducible runs
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -29,8 +36,10 @@ static void die(const char *what) {
 int main(int argc, char **argv) {
     std::string model, samp = "simple";
     bool use_evidence = false, use_solution = false;
-    long chains = 65536, groups = 0, burnin = -1, maxiters = -1, rounds = 10, seed = 42, cwin = 0;
+    long chains = 65536, groups = 0, burnin = -1, maxiters = -1, rounds = 10, seed = 42, cwin = 0, maxsecs = 0, chainadds = -1, adapt_rounds = -1;
     int device = 0;
+    bool experiment = false, rounds_given = false;
+    std::string trace_file;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -42,7 +51,12 @@ int main(int argc, char **argv) {
         else if (a == "-k" || a == "--groups") groups = std::atol(next());
         else if (a == "-b" || a == "--burnin") burnin = std::atol(next());
         else if (a == "-i" || a == "--maxiters") maxiters = std::atol(next());
-        else if (a == "-r" || a == "--rounds") rounds = std::atol(next());
+        else if (a == "-r" || a == "--rounds") { rounds = std::atol(next()); rounds_given = true; }
+        else if (a == "-x" || a == "--maxsecs") maxsecs = std::atol(next());
+        else if (a == "-a" || a == "--chainadds") chainadds = std::atol(next());
+        else if (a == "-t" || a == "--trace") trace_file = next();
+        else if (a == "--experiment") experiment = true;
+        else if (a == "--adapt-rounds") adapt_rounds = std::atol(next());
         else if (a == "-w" || a == "--cwin") cwin = std::atol(next());
         else if (a == "-e" || a == "--seed") seed = std::atol(next());
         else if (a == "--device") device = std::atoi(next());
@@ -51,6 +65,16 @@ int main(int argc, char **argv) {
     if (model.empty()) { std::fprintf(stderr, "usage: %s -m MODEL.uai [-s simple|collapsed] [-o] [-d] [-c chains] ...\n", argv[0]); return 2; }
     const bool collapsed = samp == "collapsed", adaptive = samp == "adaptive";
     if (!collapsed && !adaptive && samp != "simple") { std::fprintf(stderr, "Unknown Sampler: %s\n", samp.c_str()); return 2; }
+    if (experiment && trace_file.empty()) { std::fprintf(stderr, "Experiment mode requires a trace file\n"); return 2; }            // root.go:315-317
+    if (experiment && !use_solution) { std::fprintf(stderr, "Experiment mode scores against the solution file: add -o\n"); return 2; }
+    if (chainadds < 0) chainadds = adaptive ? 4 : 1; // (the reference's default is 1; script/experiment runs with 4)
+    if (!adaptive && chainadds != 1) { std::fprintf(stderr, "Sampler is not adaptive: ChainAdds=%ld makes no sense\n", chainadds); return 2; } // root.go:440-442
+    if (maxsecs > 0 && !rounds_given) rounds = 1L << 40; // bounded by time (and maxiters) like the reference's loop
+    FILE *trace = nullptr;
+    if (!trace_file.empty()) {
+        trace = std::fopen(trace_file.c_str(), "w"); // root.go:82-88
+        if (!trace) { std::fprintf(stderr, "Could not create trace file %s\n", trace_file.c_str()); return 2; }
+    }
 
     std::printf("Reading model from %s\n", model.c_str());
     gr_model *m = gr_model_from_file(model.c_str(), use_evidence ? 1 : 0);
@@ -94,14 +118,31 @@ int main(int argc, char **argv) {
     if (adaptive && gr_set_active_groups(s, 2)) die("Could not set the base chain count"); // root.go:360-363: at least 2 base chains
     if (gr_burnin(s, (uint64_t)burnin)) die("Failure during chain burn in");
 
+    const auto t0 = std::chrono::steady_clock::now(); // (the reference's startTime is taken before the chains are built; RunSecs here starts with the main loop)
+    if (experiment) { // root.go:455-458
+        std::fprintf(trace, "// EXPERIMENT RESULTS\n");
+        std::fprintf(trace, "RunSecs, MaxHell, NegLogMaxHell, MaxJS, NegLogMaxJS, CollapseCount\n");
+    }
     std::printf("Main Sampling Start\n");
-    const auto t0 = std::chrono::steady_clock::now();
     std::vector<double> merged(H);
     std::vector<int32_t> coll(n);
     // --maxiters counts samples over ALL chains (root.go:486-496), so one round gives every chain its share of it
     const uint64_t per_round = (uint64_t)std::max(1L, (maxiters + rounds * chains - 1) / std::max(1L, rounds * chains));
     double es[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    bool scored = false;
+    bool scored = false, keep_adapting = true;
+    auto secs = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    auto trace_line = [&](double run_time) { // root.go:520-533 / 586-597
+        int col = 0;
+        for (int v = 0; v < n; ++v) col += coll[v] ? 1 : 0;
+        std::fprintf(trace, "%.1f, %.8f, %.5f, %.8f, %.5f, %d\n", run_time, es[6], -std::log2(es[6]), es[7], -std::log2(es[7]), col);
+        return col;
+    };
+    auto error_report = [&](FILE *f, const char *prefix) { // errorReport(.., short = false, ..) (root.go:256-305)
+        std::fprintf(f, "%s ... M:mean(neg log), X:max(neg log)\n", prefix);
+        const char *titles[4] = {"MeanAbsError", "MaxAbsError", "Hellinger", "JS Diverge"};
+        for (int k = 0; k < 4; ++k)
+            std::fprintf(f, "%15s => M:%.6f(%7.3f) X:%.6f(%7.3f)\n", titles[k], es[k], -std::log2(es[k]), es[4 + k], -std::log2(es[4 + k]));
+    };
     for (long r = 0; r < rounds; ++r) {
         if (cwin > 0) {
             uint64_t ran = 0;
@@ -120,16 +161,57 @@ int main(int argc, char **argv) {
             scored = true;
         }
         std::printf("\n");
-        if (cwin <= 0 && samples > (uint64_t)maxiters) break; // root.go:493-496: sampleCount > maxIters ends the run
-        if (adaptive && r < rounds / 2) { // adaptation only during the first half of the run (root.go:469,542-547)
-            std::vector<int32_t> nv(4);
+        if (experiment) trace_line(rt);
+        bool keep_working = true;
+        if (maxsecs > 0 && rt > (double)maxsecs) keep_working = false;                                  // root.go:483-485
+        if ((cwin <= 0 || experiment || maxsecs > 0) && samples > (uint64_t)maxiters) keep_working = false; // root.go:493-496: sampleCount > maxIters
+        if (!keep_working) break;
+        // Adaptive update (root.go:541-560): while the first half of maxSecs lasts -- or, reproducibly, for the first K rounds
+        if (adaptive && keep_adapting) {
+            const bool stop = adapt_rounds >= 0 ? r >= adapt_rounds : maxsecs > 0 ? rt > (double)(maxsecs / 2) : r >= rounds / 2;
+            if (stop) { std::printf("STOPPING ADAPTATION\n"); keep_adapting = false; }
+        }
+        if (adaptive && keep_adapting) {
+            std::vector<int32_t> nv((size_t)std::max(1L, chainadds));
             uint32_t nn = 0;
             const int pre = gr_active_groups(s);
-            if (gr_adapt(s, 4, nv.data(), &nn, nullptr)) die("Adapt failed");
-            if (nn) std::printf("ADAPT: %d Chain groups (was %d)\n", gr_active_groups(s), pre);
+            if (gr_adapt(s, (uint32_t)chainadds, nv.data(), &nn, nullptr)) die("Adapt failed");
+            if (nn) std::printf("ADAPT: %d Chains (was %d)\n", gr_active_groups(s), pre);
         }
     }
+    // COMPLETED: final merge and scores (root.go:563-600)
+    const double run_time = secs();
+    {
+        gr_sampler *one[1] = {s};
+        if (gr_merge(one, 1, merged.data(), coll.data())) die("Error in final chain merge");
+        if (use_solution && gr_error_suite(n, card.data(), nullptr, fixed.data(), sol.data(), merged.data(), es)) die("Error calculating Final Score!");
+    }
     std::printf("DONE\n");
+    if (use_solution) {
+        scored = true;
+        error_report(stdout, "FINAL");
+        if (experiment) {
+            const int col = trace_line(run_time);
+            std::fprintf(trace, "// FINAL STATUS\n");
+            error_report(trace, "FINAL");
+            std::printf("COLLAPSED VARS (%d):", col);
+            for (int v = 0; v < n; ++v) if (coll[v]) std::printf(" %d", v);
+            std::printf("\n");
+        }
+    }
+    if (trace) {
+        // (the reference goes on to dump evidence, every variable and the whole model as JSON, root.go:672-716: the host's own
+        // business, nothing the device path produces beyond the merged marginals above)
+        std::fprintf(trace, "// OPERATING PARAMS\n");
+        std::fprintf(trace, "Model:                  %s\nApply Evidence:         %s\nSolution:               %s\nSampler:                %s\n", model.c_str(),
+                     use_evidence ? "true" : "false", use_solution ? "true" : "false", samp.c_str());
+        std::fprintf(trace, "Burn In:                %12ld\nConverge Win:           %12ld\nNum Base Chain:         %12ld\nChains Added per Adapt: %12ld\n", burnin, cwin,
+                     adaptive ? 2L : groups, chainadds);
+        std::fprintf(trace, "Max Iters:              %12ld\nMax Secs:               %12ld\nRnd Seed:               %12ld\nExperiment Mode:        %s\n", maxiters, maxsecs, seed,
+                     experiment ? "true" : "false");
+        std::fprintf(trace, "Device chains:          %12ld in %ld group(s) of %ld (one group per reference chain)\n", chains, groups, chains / groups);
+        std::fclose(trace);
+    }
     if (use_solution && scored) std::printf("FINAL MeanHellinger=%.8f MaxHellinger=%.8f MeanJS=%.8f MaxJS=%.8f\n", es[2], es[6], es[3], es[7]);
     gr_sampler_destroy(s);
     gr_model_destroy(m);
