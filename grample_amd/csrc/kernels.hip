@@ -245,9 +245,9 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
             float w[MAXC];
             if constexpr (PW) log_weights_pw<MAXC, (MAXC <= 16 ? 8 : (MAXC <= 32 ? 4 : 2))>(pg, tab_f, get, w, p0, p1, p2, conflict);
             else log_weights<MAXC>(pg, tab_f, get, w, p0, p1, p2, conflict);
-            double cum[MAXC > 1 ? MAXC - 1 : 1], sc;
-            cumulative<MAXC>(w, C, cum, sc);
-            return pick<MAXC>(cum, sc, C, u);
+            uint32_t cum[MAXC > 1 ? MAXC - 1 : 1], tot;
+            cumulative<MAXC>(w, C, cum, tot);
+            return pick<MAXC>(cum, tot, C, u);
         }
     };
 
@@ -396,12 +396,12 @@ __global__ void k_build_cpt(const VariantDesc vd, const uint32_t *progs_all, con
     float w[MAXC];
     bool c = false;
     log_weights<MAXC>(pg, views_all + vd.views_base, get, w, 0xffffffffu, 0xffffffffu, 0xffffffffu, c);
-    double cum[MAXC > 1 ? MAXC - 1 : 1], sc;
-    cumulative<MAXC>(w, C, cum, sc);
+    uint32_t cum[MAXC > 1 ? MAXC - 1 : 1], tot;
+    cumulative<MAXC>(w, C, cum, tot);
     uint32_t *row = cpt_all + vd.cpt_base + cp[2] + cfg * (uint32_t)(C - 1);
 #pragma unroll
     for (int i = 0; i < MAXC - 1; ++i)
-        if (i < C - 1) row[i] = threshold_u32(cum[i], sc); // u >= row[i] is the direct path's (double)u * sc >= cum[i]
+        if (i < C - 1) row[i] = threshold_u32(cum[i], tot); // u >= row[i] is the direct path's mulhi(u, tot) >= cum[i]
 }
 
 // Probe: the conditional the sampling kernels use, for one variable and one
@@ -415,11 +415,11 @@ __global__ void k_conditional(const VariantDesc vd, const uint32_t *progs_all, c
     float w[MAXC];
     bool c = false;
     log_weights<MAXC>(pg, views_all + vd.views_base, get, w, 0xffffffffu, 0xffffffffu, 0xffffffffu, c);
-    double cum[MAXC > 1 ? MAXC - 1 : 1], sc;
-    cumulative<MAXC>(w, C, cum, sc);
+    uint32_t cum[MAXC > 1 ? MAXC - 1 : 1], tot;
+    cumulative<MAXC>(w, C, cum, tot);
     double prev = 0.0;
     for (int i = 0; i < C; ++i) {
-        const double cur = (i < C - 1) ? (double)threshold_u32(cum[i < MAXC - 1 ? i : 0], sc) : 4294967296.0;
+        const double cur = (i < C - 1) ? (double)threshold_u32(cum[i < MAXC - 1 ? i : 0], tot) : 4294967296.0;
         probs[i] = (cur - prev) / 4294967296.0;
         prev = cur;
     }

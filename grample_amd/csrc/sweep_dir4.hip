@@ -159,9 +159,9 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
                 }
             }
         }
-        double cum[MAXC > 1 ? MAXC - 1 : 1], s;
-        cumulative<MAXC>(w, C, cum, s);
-        return pick<MAXC>(cum, s, C, u);
+        uint32_t cum[MAXC > 1 ? MAXC - 1 : 1], tot;
+        cumulative<MAXC>(w, C, cum, tot);
+        return pick<MAXC>(cum, tot, C, u);
     };
 
     for (uint32_t g0 = 0; g0 < nq; g0 += 4) {

@@ -42,17 +42,18 @@ template <int CTRL>
 __device__ __forceinline__ int qperm_i(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true); }
 template <int CTRL>
 __device__ __forceinline__ float qperm_f(float x) { return __int_as_float(qperm_i<CTRL>(__float_as_int(x))); }
-template <int CTRL>
-__device__ __forceinline__ double qperm_d(double x) {
-    return __hiloint2double(qperm_i<CTRL>(__double2hiint(x)), qperm_i<CTRL>(__double2loint(x)));
-}
 
 // cond.h's combination of the 4 block sums of a chain, lane c holding q_c: inclusive prefix z_c with
 //   z_1 = q1 + q0, z_2 = (q2 + q1) + q0, z_3 = (q3 + q2) + (q1 + q0)   (two Hillis-Steele steps)
 // m1 / m2 = 1.0 on the lanes that take part in a step, else 0.0 (fma(x, 1.0, y) is x + y; fma(x, 0.0, y) is y).
-__device__ __forceinline__ double quad_scan(const double q, const double m1, const double m2) {
-    const double y = fma(qperm_d<kShr1>(q), m1, q);
-    return fma(qperm_d<kShr2>(y), m2, y);
+__device__ __forceinline__ float quad_scan(const float q, const float m1, const float m2) {
+    const float y = fmaf(qperm_f<kShr1>(q), m1, q);
+    return fmaf(qperm_f<kShr2>(y), m2, y);
+}
+// the same for integers (k1 / k2 = all ones on the lanes that take part, else 0): exact, any order
+__device__ __forceinline__ int quad_scan_i(const int q, const int k1, const int k2) {
+    const int y = q + (k1 & qperm_i<kShr1>(q));
+    return y + (k2 & qperm_i<kShr2>(y));
 }
 
 } // namespace
@@ -82,24 +83,24 @@ struct StepHdr {
 // w[p][i]: f32 log sums of my 4 values of step p; returns the drawn values.
 // FULL = every step has Card 16 (all 16 values of the quad live): none of the per-value guards.
 template <int NP, bool FULL>
-__device__ __forceinline__ void pw4_cond_impl(float (&w)[NP][4], const int (&C)[NP], const uint32_t (&du)[NP], const uint32_t blk, const double m1,
-                                              const double m2, const int k1, const int k2, uint32_t (&val)[NP]) {
+__device__ __forceinline__ void pw4_cond_impl(float (&w)[NP][4], const int (&C)[NP], const uint32_t (&du)[NP], const uint32_t blk, const float m1,
+                                              const float m2, const int k1, const int k2, uint32_t (&val)[NP]) {
     bool live[NP][4];
-    double d[NP][4], t0[NP], te[NP], e4[NP][4];
+    float d[NP][4], t0[NP], te[NP], e4[NP][4];
     int guess[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             live[p][i] = FULL || (int)(4u * blk) + i < C[p];
-            w[p][i] = live[p][i] ? w[p][i] : -INFINITY; // absent values: exp -> +0.0, never floored, never drawn
+            w[p][i] = live[p][i] ? w[p][i] : -INFINITY; // absent values: exp -> +0.0, never floored, mass 0, never drawn
         }
         float m = fmaxf(fmaxf(w[p][0], w[p][1]), fmaxf(w[p][2], w[p][3]));
         m = fmaxf(m, qperm_f<kXor1>(m));
         m = fmaxf(m, qperm_f<kXor2>(m));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) d[p][i] = (double)__expf(w[p][i] - m);
-        const double tot = qperm_d<kLast>(quad_scan(((d[p][0] + d[p][1]) + d[p][2]) + d[p][3], m1, m2));
+        for (int i = 0; i < 4; ++i) d[p][i] = __expf(w[p][i] - m);
+        const float tot = qperm_f<kLast>(quad_scan(((d[p][0] + d[p][1]) + d[p][2]) + d[p][3], m1, m2));
         t0[p] = kFloorEps * tot;
         te[p] = kFloorEps * t0[p];
         guess[p] = 0;
@@ -111,9 +112,7 @@ __device__ __forceinline__ void pw4_cond_impl(float (&w)[NP][4], const int (&C)[
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             // floors in the blocks before mine = exclusive quad prefix of the guesses
-            int s1 = guess[p] + (k1 & qperm_i<kShr1>(guess[p]));
-            s1 = s1 + (k2 & qperm_i<kShr2>(s1));
-            double k = (double)(s1 - guess[p]);
+            float k = (float)(quad_scan_i(guess[p], k1, k2) - guess[p]);
             int n = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -128,14 +127,19 @@ __device__ __forceinline__ void pw4_cond_impl(float (&w)[NP][4], const int (&C)[
     }
 #pragma unroll
     for (int p = 0; p < NP; ++p) {
-        const double zq = quad_scan(((e4[p][0] + e4[p][1]) + e4[p][2]) + e4[p][3], m1, m2);
-        const double r = (double)du[p] * (qperm_d<kLast>(zq) * 0x1p-32); // r = U * total' (sampler.go:110-117), cond.h's pick()
-        const double before = qperm_d<kShr1>(zq);                         // sum of the blocks before mine (unused by block 0)
-        double cum = fma(before, m1, e4[p][0]);
+        // cond.h's masses: total' re-summed in the blocked order, n_i = floor(e_i * (2^32 - 2^20) / total' + 0.5), then integers only
+        const float scale = mass_scale(qperm_f<kLast>(quad_scan(((e4[p][0] + e4[p][1]) + e4[p][2]) + e4[p][3], m1, m2)));
+        uint32_t n4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) n4[i] = mass_of(e4[p][i], scale);
+        const int nb = (int)(((n4[0] + n4[1]) + n4[2]) + n4[3]);
+        const int zs = quad_scan_i(nb, k1, k2);                      // masses up to and including my block
+        const uint32_t r = __umulhi(du[p], (uint32_t)qperm_i<kLast>(zs)); // pick(): r = floor(u * N / 2^32)
+        uint32_t cum = (uint32_t)(zs - nb);                          // masses of the blocks before mine
         int cnt = 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            if (i > 0) cum += e4[p][i];
+            cum += n4[i];
             cnt += ((FULL ? (blk != 3u || i != 3) : (int)(4u * blk) + i < C[p] - 1) && r >= cum) ? 1 : 0;
         }
         cnt += qperm_i<kXor1>(cnt);
@@ -144,8 +148,8 @@ __device__ __forceinline__ void pw4_cond_impl(float (&w)[NP][4], const int (&C)[
 }
 
 template <int NP>
-__device__ __forceinline__ void pw4_cond(float (&w)[NP][4], const int (&C)[NP], const uint32_t (&du)[NP], const uint32_t blk, const double m1,
-                                         const double m2, const int k1, const int k2, uint32_t (&val)[NP]) {
+__device__ __forceinline__ void pw4_cond(float (&w)[NP][4], const int (&C)[NP], const uint32_t (&du)[NP], const uint32_t blk, const float m1,
+                                         const float m2, const int k1, const int k2, uint32_t (&val)[NP]) {
     bool full = true;
 #pragma unroll
     for (int p = 0; p < NP; ++p) full = full && C[p] == 16;
@@ -178,7 +182,7 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
     const uint32_t *poff = p.vprog_off + vd.progoff_base;
     const unsigned char *tab = reinterpret_cast<const unsigned char *>(p.views + vd.views_base);
     const bool counting = p.counting != 0;
-    const double m1 = blk >= 1u ? 1.0 : 0.0, m2 = blk >= 2u ? 1.0 : 0.0;
+    const float m1 = blk >= 1u ? 1.0f : 0.0f, m2 = blk >= 2u ? 1.0f : 0.0f;
     const int k1 = blk >= 1u ? -1 : 0, k2 = blk >= 2u ? -1 : 0; // the same as integer masks
 
     // the selected variable's (VarSample, sampler.go:135-174: evaluated by k_scan_vars for the whole launch) program header
