@@ -150,6 +150,9 @@ struct gr_sampler {
     bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
     bool par_lean = false;            // ... with the lean LDS layout: records always from global memory (large models)
     uint32_t par_stride = 80;         // ... bytes between the LDS state rows of consecutive variables
+    bool no_wide = false;             // fast_form 3: every automatic choice, but never the wide form (measurements)
+    bool wide_ok = false;             // ... the 8 / 16 lanes-per-chain form (k_sweep_wide) may take its place when wavefronts are what a launch lacks
+    uint32_t lpc_last = 4;            // lanes per chain of the last step-parallel launch (gr_sampler_get_info)
     bool par_tabg = false;            // ... and the threshold tables too (pools that do not fit LDS)
     uint32_t par_tab_words = 0;       // ... except the first par_tab_words words of every group's pool (split pool; 0 = all global)
     bool stg = false;                 // chain state stays in global memory (k_sweep<.., STG>): models whose state does not fit LDS
@@ -235,6 +238,13 @@ struct gr_sampler {
 // Pick block size, LDS layout and conditional path for the current images.
 void gr_sampler::configure() {
     configure_paths();
+    // the wide step-parallel form: packed records read from global memory, record offsets within the 26 bits of its plan word
+    {
+        uint64_t rec_bytes = 0;
+        for (const auto &im : image) rec_bytes += (uint64_t)im.free_vars.size() * rec_stride;
+        wide_ok = fast && par && !strict_fast && par_packed && rec_bytes < (1ull << 26) && !o.block_threads &&
+                  (o.fast_form == 0 || o.fast_form == 2 || o.fast_form >= 6) && par_rec_off <= kLdsBudget;
+    }
     // value-parallel direct form: every group pairwise, the direct path chosen, Card 9..16, whole 64-chain scan groups
     pw4 = false;
     bool all_pw = true;
@@ -603,9 +613,9 @@ void gr_sampler::rebuild() {
 
         const uint64_t waves = o.n_chains / 64u;
         uint64_t ps = (256ull << 20) / (waves * 4ull); // <= 256 MiB of plan per launch
-        ps = std::min<uint64_t>(ps, kMaxStepsPerLaunch) & ~15ull;
-        plan_steps = (uint32_t)std::max<uint64_t>(ps, 16);
-        d_plan.alloc((size_t)waves * plan_steps + 16);
+        ps = std::min<uint64_t>(ps, kMaxStepsPerLaunch) & ~63ull; // (a multiple of every form's iteration: 4, 16, 32 or 64 steps)
+        plan_steps = (uint32_t)std::max<uint64_t>(ps, 64);
+        d_plan.alloc((size_t)waves * plan_steps + 64);
     }
     if (dir4) {
         // step headers + factor entries of the direct 4-lane form, from the generic programs (compiled_model.hpp)
@@ -784,7 +794,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.par_stride = par_stride;
         // at most one wavefront per CU in the whole launch: give every wavefront a CU of its own (Grids_11 at 4 096 chains
         // 6.9e10 -> 7.2e10, Segmentation_11 6.3e10 -> 6.7e10; slower as soon as two wavefronts would have to share a CU's LDS)
-        f.par_spread = act / 64u * 4u <= 256u ? 1u : 0u;
+        f.par_spread = act / 64u * 4u <= 256u ? 1u : 0u; // (set again below for the wide form)
         f.par_recmode = par_lean ? 2u : o.fast_form >= 4 && o.fast_form <= 6 ? o.fast_form - 4u : 99u;
         if (!d_err.p) {
             d_err.alloc(1);
@@ -800,7 +810,26 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.counting = p.counting; f.lds_hist_off = lds_hist_off; f.lds_tab_off = lds_tab_off; f.lds_plan_off = lds_plan_off;
         f.recs_par = d_recs_par.p; f.par_hist_off = par_hist_off; f.par_tab_off = par_tab_off; f.par_rec_off = par_rec_off;
         f.par_plan_off = par_plan_off; f.par_scr_off = par_scr_off;
-        const uint64_t gran = strict_fast ? 4 : par ? 16 : 4; // steps per inner iteration of the fast kernels
+        // Lanes per chain of the step-parallel form for THIS launch: 4 (k_sweep_par4), or 8 / 16 (k_sweep_wide) while the launch would
+        // otherwise leave SIMDs short of wavefronts.  Wider rounds cost more re-gather passes per update (Grids: x1.13 with 8 lanes,
+        // x1.3 with 16), so: 16 lanes up to 2 wavefronts per SIMD (1 024 SIMDs), 8 lanes up to 4; logged windows (gr_advance_chain)
+        // always run the 4-lane form.  All forms give the same results bit for bit, so launches of a run may differ.
+        uint32_t lpc = 4;
+        if (par && wide_ok && !no_wide && !cur_log && !cur_limit) {
+            const uint32_t groups = act / 64u;
+            // measured (scripts/dev_wide.py -> profiles/r03_dev_wide.txt): 16 lanes pay while 16 x groups <= 4 096 wavefronts AND the
+            // block's LDS footprint lets a CU hold four of them (one-wavefront blocks spread over the CUs); 8 lanes while 8 x groups
+            // <= 4 096; beyond that the 4-lane form has the chip full and the wider forms' extra passes only cost
+            if (o.fast_form == 8) lpc = 8;
+            else if (o.fast_form == 9) lpc = 16;
+            else if (o.fast_form == 0 && groups * 16u <= 4096u && par_rec_off * 4u <= kLdsBudget) lpc = 16;
+            // (records of more than 8 slots make the wide kernel's two record sets cost more than 128 registers: a CU then holds ONE
+            // 512-lane block -- fine while there is at most one per CU to run, a loss beyond: Segmentation_11 at 32 768 chains 4.1e11
+            // with 4 lanes, 3.1e11 with 8)
+            else if (o.fast_form == 0 && groups * 8u <= (fast_slots <= 8 ? 4096u : 2048u)) lpc = 8;
+        }
+        if (par) lpc_last = lpc;
+        const uint64_t gran = strict_fast ? 4 : par ? 4u * lpc : 4; // steps per inner iteration of the fast kernels
         uint64_t left = updates;
         const uint64_t head = std::min<uint64_t>(left, (gran - (step % gran)) % gran);
         if (head) { generic_small(head); left -= head; }
@@ -824,6 +853,16 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 }
                 hip_check(launch_sweep_strict(f, fast_slots, par_packed, quad_blocks ? act / 256u : act / 64u, quad_blocks ? 256u : 64u,
                                               quad_blocks ? par_lds + 3u * region : par_lds, stream), "k_sweep_strict launch");
+                step += n; left -= n; launches_last++;
+                continue;
+            }
+            if (par && lpc > 4) {
+                // one wavefront per block while the whole launch has fewer wavefronts than the chip has SIMDs (every wavefront its own
+                // CU's LDS pipe, as for the 4-lane form); else 64 x lpc lanes per block
+                // ... and the CUs' LDS holds all of those blocks at once (each stages its own copy of the tables)
+                f.par_spread = (act / 64u * lpc <= 1024u && (uint64_t)(act / 64u) * lpc <= 256ull * (kLdsBudget / par_rec_off)) ? 1u : 0u;
+                hip_check(launch_scan_plan_wide(f, (int)lpc, stream), "k_scan_plan_wide launch");
+                hip_check(launch_sweep_wide(f, (int)lpc, fast_slots, act / 64u, par_rec_off, stream), "k_sweep_wide launch");
                 step += n; left -= n; launches_last++;
                 continue;
             }
@@ -1063,6 +1102,7 @@ GR_VISIBLE gr_sampler *gr_sampler_create(const gr_model *m, const gr_sampler_opt
         if (opts->device < 0 || opts->device >= ndev) throw Error(GR_E_NO_DEVICE, "device ordinal out of range");
         auto s = std::make_unique<gr_sampler>();
         s->o = *opts;
+        if (s->o.fast_form == 3) { s->o.fast_form = 0; s->no_wide = true; }
         s->use();
         hip_check(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking), "hipStreamCreate");
         hip_check(hipEventCreate(&s->ev0), "hipEventCreate");
@@ -1830,7 +1870,7 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         if (s->dirty) { s->use(); s->configure(); }
         out->block_threads = s->T; out->n_blocks = s->blocks;
         out->lds_bytes = s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->dir4 ? s->dir_lds : s->lds; // of the kernel that actually runs
-        if (s->fast && s->par) { out->block_threads = s->strict_fast ? s->T : 256u; out->n_blocks = s->active_chains() / 64u; }
+        if (s->fast && s->par) { out->block_threads = s->strict_fast ? s->T : 64u * s->lpc_last; out->n_blocks = s->active_chains() / 64u; } // (64 x lanes per chain of the last launch)
         out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });

@@ -909,6 +909,247 @@ hipError_t launch_sweep_par4_p4(const FastParams &p, int slots, uint32_t blocks,
     default: return hipErrorInvalidValue;
     }
 }
+#elif GR_PAR4_PART == 5
+// ---------------------------------------------------------------------------
+// K1, WIDE step-parallel form: 8 or 16 lanes per chain (round 3).
+//
+// k_sweep_par4 turns 64 chains into 4 wavefronts.  Launches that still leave the chip under-filled with that -- BASELINE config 1
+// (Grids_11, 4 096 chains = 256 wavefronts for 1 024 SIMDs), the first rounds of an adaptive run (2 groups), collapsed
+// Segmentation_11 (LDS lets a CU hold two 64-chain blocks = 2 wavefronts per SIMD) -- get LPC = 8 or 16 lanes per chain here: a
+// block of 64 x LPC lanes still owns the 64 chains of one scan group (same LDS footprint), but LPC consecutive steps of every
+// chain are gathered, drawn and committed side by side, so the same chains are 2x / 4x the wavefronts.  The dependency levels
+// of the plan (k_scan_plan_wide) now span LPC steps: more re-gather passes per 64 updates (Grids: 1.26 with 4 steps side by
+// side, 1.85 with 8, 2.7 with 16), which is why this form is only chosen while wavefronts are what is missing.
+//   lanes     lane = slot * W + c, W = 64 / LPC chains per wavefront; slot s handles step j(s) = (s % E) * 4 + s / E of a round,
+//             E = LPC / 4 -- chosen so that the draw transpose stays the two lane-swap pairs of k_sweep_par4: lane slot s computes
+//             the Philox call of quad Q0 + s (slot bits = (k1 k0 | j_hi)), the swaps exchange (k1 k0) with the word index
+//             (j1 j0), and lane slot (j1 j0 | j_hi) ends up with word (j1 j0) of quads Q0 + 4 k' + .. for the rounds k' = 0 .. 3
+//   iteration 4 rounds of LPC steps (one Philox call per lane); records and plan words from global memory, one iteration ahead
+// Counting, records, threshold tables (LDS, global, split) and the commit order are k_sweep_par4's: bit-identical results.
+// No draw log: gr_advance_chain windows run the 4-lane form (same results, so the forms mix freely).
+constexpr uint32_t kWideOffMask = 0x03ffffc0u; // plan word of the wide form: record offset (< 64 MiB, multiple of 64) in bits 6..25,
+                                               // level in bits 0..3, highest level of the round in bits 26..29, bits 30 / 31 as kPlanDepsBit / kPlanLevelBit
+
+template <int LPC>
+__global__ void __launch_bounds__(256) k_scan_plan_wide(const FastParams p) {
+    extern __shared__ unsigned short sp_tab[];
+    const uint32_t ng = p.n_steps / (uint32_t)LPC; // rounds in this launch
+    const uint32_t wave = blockIdx.y, gi = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t variant = (wave * 64u) / p.chains_per_variant;
+    const VariantDesc vd = p.variants[variant];
+    const uint32_t S = 2u + p.plan_slots;
+    for (uint32_t k = threadIdx.x; k < vd.n_free; k += 256u) {
+        const uint32_t v = p.free_vars[vd.free_base + k];
+        const uint32_t *cp = p.cprogs + vd.cprog_base + p.cprog_off[vd.cprogoff_base + v];
+        const uint32_t nn = (cp[0] >> 8) & 0xffu;
+        sp_tab[k * S] = (unsigned short)v;
+        sp_tab[k * S + 1u] = (unsigned short)nn;
+        for (uint32_t i = 0; i < nn; ++i) sp_tab[k * S + 2u + i] = (unsigned short)cp[3 + 2 * i];
+    }
+    __syncthreads();
+    if (gi >= ng) return;
+    const uint64_t q0 = ((((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2) + (uint64_t)gi * (LPC / 4);
+    const uint64_t gchain0 = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + (uint64_t)wave * 64u;
+    uint32_t k[LPC], v[LPC], level[LPC], maxlv = 0;
+#pragma unroll
+    for (int c = 0; c < LPC / 4; ++c) {
+        const uint64_t q = q0 + (uint64_t)c;
+        const u32x4 sc = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)(gchain0 >> 6), DOM_SCAN, p.seed_lo, p.seed_hi);
+        k[4 * c] = mul_hi_u32(sc.x, vd.n_free); k[4 * c + 1] = mul_hi_u32(sc.y, vd.n_free);
+        k[4 * c + 2] = mul_hi_u32(sc.z, vd.n_free); k[4 * c + 3] = mul_hi_u32(sc.w, vd.n_free);
+    }
+#pragma unroll
+    for (int j = 0; j < LPC; ++j) {
+        const unsigned short *e = sp_tab + k[j] * S;
+        v[j] = e[0];
+        // level of step j inside its round: 1 + the highest level of an earlier step that updates the same variable or one of
+        // its neighbours (k_scan_plan's rule over LPC steps instead of 4)
+        const uint32_t nn = e[1];
+        uint32_t lv = 0;
+#pragma unroll
+        for (int pj = 0; pj < j; ++pj)
+            if (v[pj] == v[j]) lv = max(lv, level[pj] + 1u);
+        for (uint32_t i = 0; i < nn; ++i) {
+            const uint32_t u = e[2 + i];
+#pragma unroll
+            for (int pj = 0; pj < j; ++pj)
+                if (u == v[pj]) lv = max(lv, level[pj] + 1u);
+        }
+        level[j] = lv;
+        maxlv = max(maxlv, lv);
+    }
+    uint4 *dst = reinterpret_cast<uint4 *>(p.plan + (size_t)wave * p.plan_pitch) + (size_t)gi * (LPC / 4);
+#pragma unroll
+    for (int c = 0; c < LPC / 4; ++c) {
+        uint32_t o[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = 4 * c + t;
+            o[t] = (vd.rec_base + k[j]) * p.rec_stride | level[j] | (maxlv << 26) | (level[j] ? kPlanLevelBit : 0u) | (maxlv ? kPlanDepsBit : 0u);
+        }
+        dst[c] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+template <int LPC, int SLOTS, int MODE, int TABG> // MODE 0: burn-in, 1: count
+__global__ void __launch_bounds__(64 * LPC) k_sweep_wide(const FastParams p) {
+    constexpr bool COUNT = MODE != 0, PACKED = true;
+    constexpr uint32_t W = 64u / LPC, E = LPC / 4u;
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, nthr = blockDim.x;
+    const bool spread = nthr == 64u;                                   // one wavefront per block (launches with few groups)
+    const uint32_t group = spread ? blockIdx.x / LPC : blockIdx.x;    // 64-chain scan group
+    const uint32_t wave = spread ? blockIdx.x % LPC : tid >> 6;       // which W chains of the group
+    const uint32_t slot = lane / W;                                    // lane slot
+    const uint32_t j = (slot % E) * 4u + slot / E;                     // the step of a round this lane slot handles
+    const uint32_t cb = wave * W + (lane % W);                         // chain inside the group
+    const uint32_t chain = group * 64u + cb;
+    const uint32_t variant = (group * 64u) / p.chains_per_variant;
+    const VariantDesc vd = p.variants[variant];
+    {   // stage the threshold tables (all, or the LDS part of a split pool), this block's chains, zero the block histogram
+        const uint32_t n4 = ((TABG == 2 ? min(vd.cpt_len, p.par_tab_words) : vd.cpt_len) + 3u) >> 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + p.par_tab_off);
+        if constexpr (TABG != 1)
+            for (uint32_t i = tid; i < n4; i += nthr) dst[i] = src[i];
+        for (uint32_t v = slot; v < p.n_vars; v += LPC) lds[v * p.par_stride + cb] = p.state[(size_t)v * p.pitch + chain];
+        uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.par_hist_off);
+        for (uint32_t i = tid; i < 2u * vd.n_free; i += nthr) h[i] = 0;
+    }
+    __syncthreads();
+    // the global records hold offsets into the dynamic LDS array, used as absolute LDS addresses (see k_sweep_par4)
+    if (lds_addr_of(lds) != 0u) {
+        if (threadIdx.x == 0) atomicOr(p.err, 1u);
+        return;
+    }
+    const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
+    const uint64_t q0 = (((uint64_t)p.step0_hi << 32) | p.step0_lo) >> 2;
+    const uint32_t n_it = p.n_steps / (4u * LPC);  // iterations: 4 rounds of LPC steps each
+    const uint32_t n_rounds = n_it * 4u;
+    const unsigned char *lds_c = lds + cb;
+    const unsigned char *tabp = TABG ? reinterpret_cast<const unsigned char *>(p.cpt + vd.cpt_base) : lds;
+    const unsigned char *recs_g = reinterpret_cast<const unsigned char *>(p.recs_par);
+    const bool tail = (lane % W) == W - 1u;
+    // ones of my lane slot = popcount of the compare mask's W bits of my slot
+    const unsigned long long slot_mask = ((1ull << W) - 1ull) << (slot * W);
+    const uint32_t rm_lo = (uint32_t)slot_mask, rm_hi = (uint32_t)(slot_mask >> 32);
+
+    const __amdgpu_buffer_rsrc_t plan_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint32_t *>(p.plan + (size_t)group * p.plan_pitch), 0, 0x7fffffff, 0x00020000);
+    const uint32_t j4 = j * 4u;
+    uint32_t pwa[4] = {0, 0, 0, 0};
+    auto prefetch_plan = [&](const uint32_t round0) { // the plan words of rounds round0 .. round0 + 3 (never past the plan)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pwa[k] = __builtin_amdgcn_raw_buffer_load_b32(plan_rsrc, j4, min(round0 + (uint32_t)k, n_rounds - 1u) * (4u * LPC), 0);
+    };
+    uint32_t pwA[4] = {0, 0, 0, 0}, pwB[4] = {0, 0, 0, 0};
+    RecL<SLOTS, PACKED> rA[4], rB[4];
+    auto prefetch = [&](RecL<SLOTS, PACKED> (&rx)[4], uint32_t (&pwx)[4]) { // the iteration whose plan words are in pwa
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            pwx[k] = pwa[k];
+            const unsigned char *ga = recs_g + (pwx[k] & kWideOffMask);
+            rx[k].h = *reinterpret_cast<const uint4 *>(ga);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(rx[0].s) / sizeof(uint4)); ++i) rx[k].s[i] = *reinterpret_cast<const uint4 *>(ga + 16 + 16 * i);
+        }
+    };
+    prefetch_plan(0); prefetch(rA, pwA); prefetch_plan(4);
+
+    auto iteration = [&](const uint32_t it, RecL<SLOTS, PACKED> (&rc)[4], uint32_t (&pwc)[4], RecL<SLOTS, PACKED> (&rx)[4], uint32_t (&pwx)[4]) {
+        // draws: my Philox call is quad it * LPC + slot; two lane-swap pairs leave U[k] = my word of round k (see the header)
+        const uint64_t q = q0 + (uint64_t)it * LPC + slot;
+        const u32x4 Wd = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
+        uint32_t U[4];
+        {
+            const auto a = __builtin_amdgcn_permlane32_swap(Wd.x, Wd.z, false, false);
+            const auto b = __builtin_amdgcn_permlane32_swap(Wd.y, Wd.w, false, false);
+            const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+            const auto d = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+            U[0] = c[0]; U[1] = c[1]; U[2] = d[0]; U[3] = d[1];
+        }
+        prefetch(rx, pwx); prefetch_plan(it * 4u + 8u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const RecL<SLOTS, PACKED> r = rc[k];
+            const uint32_t pw = pwc[k];
+            const bool val = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
+            unsigned long long drawn = __ballot(val);
+            if (pw < kPlanLevelBit) lds[r.h.x + cb] = val ? (unsigned char)1 : (unsigned char)0; // level 0: commit in the first pass
+            if (__any(pw >= kPlanDepsBit)) { // the round has steps that do not commute (uniform: the same bits in all its words)
+                const uint32_t lv = pw & 15u;
+                const uint32_t maxlv = (uni_b(pw) >> 26) & 15u;
+                for (uint32_t level = 1; level <= maxlv; ++level) {
+                    // (the re-gather reads bytes other lanes have just committed: in-order LDS in hardware, the fence for the
+                    // compiler -- see k_sweep_par4)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    const bool v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
+                    if (lv == level) lds[r.h.x + cb] = v2 ? (unsigned char)1 : (unsigned char)0;
+                    const unsigned long long mine = __ballot(lv == level);
+                    drawn = (drawn & ~mine) | (__ballot(v2) & mine);
+                }
+            }
+            if constexpr (COUNT) {
+                const uint32_t s1 = (uint32_t)__builtin_popcount(((uint32_t)drawn & rm_lo) | ((uint32_t)(drawn >> 32) & rm_hi));
+                if (tail)
+                    __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>((uintptr_t)r.h.y),
+                                           ((unsigned long long)s1 << 32) | (unsigned long long)(W - s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
+    for (uint32_t it = 0; it < n_it; it += 2) {
+        iteration(it, rA, pwA, rB, pwB);
+        if (it + 1u < n_it) iteration(it + 1u, rB, pwB, rA, pwA);
+    }
+
+    for (uint32_t v = slot; v < p.n_vars; v += LPC) p.state[(size_t)v * p.pitch + chain] = lds[v * p.par_stride + cb];
+    if constexpr (COUNT) {
+        __syncthreads();
+        const uint32_t *h = reinterpret_cast<const uint32_t *>(lds + p.par_hist_off);
+        unsigned long long *gc = p.counts + (size_t)variant * p.H;
+        flush_rank_hist(p, vd, h, gc, tid, nthr);
+    }
+}
+
+template <int LPC, int SLOTS>
+static hipError_t launch_wide_t(const FastParams &p, uint32_t groups, uint32_t lds, hipStream_t s) {
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(p.par_spread ? groups * LPC : groups), dim3(p.par_spread ? 64 : 64 * LPC), lds, s, p);
+        return hipGetLastError();
+    };
+    if (p.tab_global && p.par_tab_words) return p.counting ? go(&k_sweep_wide<LPC, SLOTS, 1, 2>) : go(&k_sweep_wide<LPC, SLOTS, 0, 2>);
+    if (p.tab_global) return p.counting ? go(&k_sweep_wide<LPC, SLOTS, 1, 1>) : go(&k_sweep_wide<LPC, SLOTS, 0, 1>);
+    return p.counting ? go(&k_sweep_wide<LPC, SLOTS, 1, 0>) : go(&k_sweep_wide<LPC, SLOTS, 0, 0>);
+}
+
+template <int LPC>
+static hipError_t launch_wide_l(const FastParams &p, int slots, uint32_t groups, uint32_t lds, hipStream_t s) {
+    // slot classes: padding slots read the variable's own row with multiplier 0 (harmless)
+    if (slots <= 4) return launch_wide_t<LPC, 4>(p, groups, lds, s);
+    if (slots <= 8) return launch_wide_t<LPC, 8>(p, groups, lds, s);
+    if (slots <= 12) return launch_wide_t<LPC, 12>(p, groups, lds, s);
+    if (slots <= 16) return launch_wide_t<LPC, 16>(p, groups, lds, s);
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_sweep_wide(const FastParams &p, int lpc, int slots, uint32_t groups, uint32_t lds, hipStream_t s) {
+    return lpc == 8 ? launch_wide_l<8>(p, slots, groups, lds, s) : lpc == 16 ? launch_wide_l<16>(p, slots, groups, lds, s) : hipErrorInvalidValue;
+}
+
+hipError_t launch_scan_plan_wide(const FastParams &p, int lpc, hipStream_t s) {
+    const uint32_t n_waves = p.n_chains >> 6, ng = p.n_steps / (uint32_t)lpc;
+    if (n_waves == 0 || ng == 0) return hipSuccess;
+    const size_t lds = (size_t)p.plan_nfree_max * (2u + p.plan_slots) * sizeof(unsigned short);
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3((ng + 255u) / 256u, n_waves), dim3(256), lds, s, p);
+        return hipGetLastError();
+    };
+    return lpc == 8 ? go(&k_scan_plan_wide<8>) : lpc == 16 ? go(&k_scan_plan_wide<16>) : hipErrorInvalidValue;
+}
 #else
 hipError_t launch_sweep_par4_p1(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s);
 hipError_t launch_sweep_par4_p2(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s);

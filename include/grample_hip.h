@@ -125,7 +125,10 @@ typedef struct gr_sampler_opts {
                                 of a quad; large-Card pairwise models on the direct path: one lane per block of 4 values);
                                 4, 5, 6 = 4 lanes per chain with the step records read from LDS one by one / from LDS together /
                                 from global memory one iteration ahead (2 picks by occupancy); 7 = as 6 with the threshold pool split
-                                between LDS (its first half) and global memory whatever the occupancy (cross-checks of that kernel) */
+                                between LDS (its first half) and global memory whatever the occupancy (cross-checks of that kernel);
+                                3 = as 0, but never more than 4 lanes per chain (measurements); 8, 9 = 8 / 16 lanes per chain (binary memoised models; chosen automatically while a launch has too few
+                                wavefronts for the chip: small chain counts, the first rounds of an adaptive run, models whose LDS
+                                footprint leaves a CU two 64-chain blocks) */
 } gr_sampler_opts;
 
 /* NewGibbsSimple for every chain (gibbs-simple.go:25-115): clones the model,

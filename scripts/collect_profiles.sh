@@ -28,6 +28,7 @@ python3 $R/scripts/bench_configs.py > $O/configs.jsonl 2> $O/configs.err || exit
 echo "configs done"
 python3 $R/scripts/dev_time.py > $O/dev_time.txt 2>&1
 python3 $R/scripts/dev_od.py > $O/dev_od.txt 2>&1
+python3 $R/scripts/dev_wide.py > $O/dev_wide.txt 2>&1
 python3 $R/scripts/dev_all_models.py 32768 > $O/all_models_32768.txt 2>&1
 python3 $R/scripts/parity_configs.py > $O/parity_configs.jsonl 2> $O/parity_configs.err
 for spec in "ObjectDetection_13.uai 256 50 400" "Segmentation_11.uai 256 20 100" "Grids_13.uai 256 20 200"; do

@@ -270,12 +270,14 @@ def test_all_kernel_forms_agree_bit_for_bit(res_dir):
     m = g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_13.uai"))
     runs = {}
     for path, kw in {0: dict(flags=g.GR_FLAG_DIRECT), 1: dict(block_threads=64), 2: dict(fast_form=1), 3: dict(fast_form=2),
-                     34: dict(fast_form=4), 35: dict(fast_form=5), 36: dict(fast_form=6), 37: dict(fast_form=7)}.items():
+                     34: dict(fast_form=4), 35: dict(fast_form=5), 36: dict(fast_form=6), 37: dict(fast_form=7),
+                     38: dict(fast_form=8), 39: dict(fast_form=9)}.items():
         s = g.HIPChains(m, 2048, seed=9, chain_offset=64 * 3, **kw)
         s.BurnIn(333); s.Advance(1001); s.Advance(2 * 4096 + 3)
-        runs[path] = (s.info()["path"], s.counts(), np.stack([s.LastSample(c) for c in (0, 63, 64, 1000, 2047)]))
-    assert [runs[k][0] for k in sorted(runs)] in ([0, 1, 2, 3, 3, 3, 3, 3], [0, 2, 2, 3, 3, 3, 3, 3])
-    for k in (1, 2, 3, 34, 35, 36, 37):  # 34..36: the 4-lane form's three record sources; 37: split threshold pool
+        runs[path] = (s.info()["path"], s.counts(), np.stack([s.LastSample(c) for c in (0, 63, 64, 1000, 2047)]), s.info()["block_threads"])
+    assert [runs[k][0] for k in sorted(runs)] in ([0, 1, 2, 3, 3, 3, 3, 3, 3, 3], [0, 2, 2, 3, 3, 3, 3, 3, 3, 3])
+    assert [runs[k][3] for k in (36, 38, 39)] == [256, 512, 1024]  # 4, 8 and 16 lanes per chain
+    for k in (1, 2, 3, 34, 35, 36, 37, 38, 39):  # 34..36: the 4-lane form's three record sources; 37: split threshold pool; 38, 39: wide forms
         assert np.array_equal(runs[0][1], runs[k][1]), k
         assert np.array_equal(runs[0][2], runs[k][2]), k
 
