@@ -17,6 +17,7 @@ GR_FLAG_SEQUENTIAL = 1 << 1
 GR_FLAG_CHAIN_PER_LANE = 1 << 2
 GR_FLAG_SCAN_PER_CHAIN = 1 << 3
 GR_FLAG_STATE_GLOBAL = 1 << 4
+GR_FLAG_SCAN_SYSTEMATIC = 1 << 5
 
 ERROR_KEYS = ["MeanMeanAbsError", "MeanMaxAbsError", "MeanHellinger", "MeanJSDiverge",
               "MaxMeanAbsError", "MaxMaxAbsError", "MaxHellinger", "MaxJSDiverge"]

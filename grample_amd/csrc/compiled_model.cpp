@@ -42,6 +42,28 @@ VariantImage CompileVariant(const Model &m, const CompileLimits &lim) {
         if (m.Vars[v].FixedVal < 0 && !m.Vars[v].Collapsed) im.free_vars.push_back((uint32_t)v);
     if (im.free_vars.empty()) throw Error(GR_E_INVALID, "No Variables to select");
 
+    {   // ---- systematic scan order: greedy colouring in ascending id, smallest colour no neighbour uses
+        const auto nbrs = VarNeighbors(m);
+        std::vector<int> color(N, -1);
+        int n_col = 0;
+        for (uint32_t v : im.free_vars) {
+            std::vector<char> used((size_t)n_col + 1, 0);
+            for (int u : nbrs[v])
+                if (u != (int)v && color[u] >= 0) used[(size_t)color[u]] = 1;
+            int c = 0;
+            while (used[(size_t)c]) ++c;
+            color[v] = c;
+            n_col = std::max(n_col, c + 1);
+        }
+        im.color_off.assign((size_t)n_col + 1, 0);
+        for (int c = 0; c < n_col; ++c) {
+            im.color_off[(size_t)c] = (uint32_t)im.sys_order.size();
+            for (uint32_t v : im.free_vars)
+                if (color[v] == c) im.sys_order.push_back(v);
+        }
+        im.color_off[(size_t)n_col] = (uint32_t)im.sys_order.size();
+    }
+
     // ---- direct programs + view tables
     for (int v = 0; v < N; ++v) {
         const Variable &var = m.Vars[v];

@@ -51,6 +51,10 @@ struct VariantImage {
     uint32_t max_view_stride = 0;   // largest view-table stride (floats) of an "other" scope variable
     uint32_t max_neighbours = 0;    // largest blanket (free variables only, the variable itself excluded)
     std::vector<uint32_t> free_vars;// selectable variables: FixedVal < 0 and not Collapsed (sampler.go:146-156)
+    // GR_FLAG_SCAN_SYSTEMATIC: the selectable variables in the order a systematic sweep updates them -- by colour class of a
+    // greedy colouring of the factor graph (variables of one class share no factor, so their updates commute), ascending id
+    // inside a class; color_off[k] .. color_off[k + 1] = the positions of class k in sys_order
+    std::vector<uint32_t> sys_order, color_off;
     bool cpt_ok = false;            // memoised path available
     std::vector<uint32_t> cprog;    // memoised programs
     std::vector<uint32_t> cprog_off;// [n_vars]

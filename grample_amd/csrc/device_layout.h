@@ -20,6 +20,7 @@ struct VariantDesc {
     uint32_t pprog_base;   // words, into pprogs (pairwise fixed-stride direct programs); pprog_off shares progoff_base
     uint32_t dent_base, dent_len; // 16-byte units, into the factor entries of the step-parallel direct form (k_sweep_dir4)
     uint32_t vprog_base;   // words, into vprogs (value-parallel pairwise programs, k_sweep_pw4); vprog_off shares progoff_base
+    uint32_t csl_base, csl_n; // k_sweep_chroma: first lane slot of this group (64 entries each) in chroma_slots, number of lane slots
 };
 
 struct SweepParams {
@@ -63,6 +64,7 @@ struct SweepParams {
     uint32_t win_off;
     uint32_t log_vals;          // bytes per logged step: 1 = the number of ones (all-binary models), else max Card (one count per value)
     uint32_t log_rows;          // rows per 64-chain group in the log (4 when the 4-lane form writes it); this kernel uses the first
+    const uint32_t *sys_order;  // GR_FLAG_SCAN_SYSTEMATIC: the sweep order (same pool layout as free_vars), else null
 };
 
 // Fast binary/memoised path (sweep_bin.hip).  A RECORD is one 64-byte line per
@@ -115,6 +117,12 @@ struct FastParams {
                                  // offset inside the group's pool); records from global memory too (record mode 2)
     uint32_t par_spread;         // k_sweep_par4: 1 = launch the 4 wavefronts of a 64-chain group as 4 blocks of 64 lanes (few groups: spread
                                  // them over the CUs), 0 = one block of 256 lanes per group
+    // k_sweep_chroma (systematic scan): lane slots (64 entries per slot: index into the group's free list, or 0xffffffff), its records
+    // (state offsets inside a chain's row instead of row offsets), LDS layout {chain rows, tables}, chains (= wavefronts) per block
+    const uint32_t *chroma_slots;
+    const uint32_t *recs_chroma;
+    const uint32_t *sys_pos;     // position in the sweep order of every entry of the free list (the draw stream's key)
+    uint32_t chroma_row, chroma_tab_off, chroma_wpb, chroma_hist_off;
     uint32_t par_tab_words;      // k_sweep_par4 with tab_global: the first par_tab_words words of every group's pool are staged in LDS all
                                  // the same (split pool; record word 2 carries bit 31 for a table that stayed in global memory)
 };

@@ -171,8 +171,12 @@ __device__ __forceinline__ void log_weights_pw(cu32p pg, const float *tab, Gette
 // STG: the chain state stays in global memory as it is laid out there -- state[var][chain], one coalesced 64-byte row per
 // wavefront and variable -- instead of being staged in LDS: for models whose state does not fit LDS (n_vars * 64 B per
 // wavefront > 160 KiB) and as GR_FLAG_STATE_GLOBAL for cross-checks.  Same arithmetic, same order: bit-identical results.
-template <int MAXC, bool CPT, bool TAB_LDS, bool PW, bool PC, bool LOG = false, bool STG = false>
+// SCAN 0: one variable per 64-chain group and step (shared scan); 1 = PC, every chain its own variable; 2 = SYS,
+// GR_FLAG_SCAN_SYSTEMATIC: update t resamples variable sys_order[t mod n] with the draw philox_sys_draw(t / n, t mod n, chain) --
+// the cross-check of k_sweep_chroma and its head / tail launches (instantiated for the direct back-end only).
+template <int MAXC, bool CPT, bool TAB_LDS, bool PW, int SCAN, bool LOG = false, bool STG = false>
 __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
+    constexpr bool PC = SCAN == 1, SYS = SCAN == 2;
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t T = blockDim.x;
     const uint32_t tid = threadIdx.x;
@@ -287,18 +291,40 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
         }
     };
 
+    // SYS: position in the sweep order and sweep number of the first step of the current quad (uniform), kept by increments
+    uint32_t sys_pos = 0;
+    uint64_t sys_sweep = 0;
+    if constexpr (SYS) {
+        const uint64_t s_first = (step0 >> 2) << 2;
+        sys_sweep = s_first / vd.n_free;
+        sys_pos = (uint32_t)(s_first - sys_sweep * vd.n_free);
+    }
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
+        uint32_t su[4] = {0, 0, 0, 0}, du[4];
+        uint32_t v[4];
+        cu32p pg[4];
+        bool valid[4];
+        if constexpr (SYS) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint64_t s = (q << 2) + j;
+                valid[j] = (s >= step0) && (s < step1);
+                v[j] = as_const(p.sys_order + vd.free_base)[sys_pos];
+                pg[j] = as_const(progs) + as_const(poff)[v[j]];
+                const u32x4 dr = philox_sys_draw(sys_sweep, sys_pos, gchain, p.seed_lo, p.seed_hi);
+                const uint32_t w = (uint32_t)sys_sweep & 3u;
+                du[j] = w == 0 ? dr.x : w == 1 ? dr.y : w == 2 ? dr.z : dr.w;
+                if (++sys_pos == vd.n_free) { sys_pos = 0; ++sys_sweep; }
+            }
+        } else {
         // which variable each of the next 4 steps updates: wave-uniform stream -> SALU
         const u32x4 sc = PC ? philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_SCAN_CHAIN + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi)
                             : philox4x32_10<true>(q_lo, q_hi, wave_gid, DOM_SCAN, p.seed_lo, p.seed_hi);
         // the 4 categorical draws of this chain
         const u32x4 dr = philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
-        const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w};
-        const uint32_t du[4] = {dr.x, dr.y, dr.z, dr.w};
-        uint32_t v[4];
-        cu32p pg[4];
-        bool valid[4];
+        su[0] = sc.x; su[1] = sc.y; su[2] = sc.z; su[3] = sc.w;
+        du[0] = dr.x; du[1] = dr.y; du[2] = dr.z; du[3] = dr.w;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint64_t s = (q << 2) + j;
@@ -307,6 +333,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
             if constexpr (PC) v[j] = as_const(freev)[mul_hi_u32(su[j], vd.n_free)];
             else v[j] = as_const(freev)[uni(mul_hi_u32(uni(su[j]), vd.n_free))];
             pg[j] = as_const(progs) + as_const(poff)[v[j]];
+        }
         }
         // Phase A: conditionals of all 4 steps from the current state.  Step j's
         // result is exact unless an earlier step of the quad updates one of its
@@ -828,7 +855,7 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
         else { constexpr int MC = 64; __VA_ARGS__; }               \
     } while (0)
 
-template <int MC, bool CPT, bool TL, bool PW, bool PC = false, bool LOG = false, bool STG = false>
+template <int MC, bool CPT, bool TL, bool PW, int PC = 0, bool LOG = false, bool STG = false>
 static hipError_t launch_sweep_t(const SweepParams &p, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sweep<MC, CPT, TL, PW, PC, LOG, STG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -842,12 +869,14 @@ static hipError_t launch_sweep_mc(const SweepParams &p, bool cpt, bool tab_lds, 
                                   uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t s) {
     if (state_global) // state in global memory: tables from global memory too; no strict mode, no draw log
         return (p.log || per_chain || tab_lds) ? hipErrorInvalidValue
-               : cpt ? launch_sweep_t<MC, true, false, false, false, false, true>(p, blocks, threads, lds_bytes, s)
-               : pairwise ? launch_sweep_t<MC, false, false, true, false, false, true>(p, blocks, threads, lds_bytes, s)
-                          : launch_sweep_t<MC, false, false, false, false, false, true>(p, blocks, threads, lds_bytes, s);
-    if (p.log) return (per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, false, true>(p, blocks, threads, lds_bytes, s);
-    if (per_chain) return tab_lds ? launch_sweep_t<MC, false, true, false, true>(p, blocks, threads, lds_bytes, s)
-                                  : launch_sweep_t<MC, false, false, false, true>(p, blocks, threads, lds_bytes, s);
+               : cpt ? launch_sweep_t<MC, true, false, false, 0, false, true>(p, blocks, threads, lds_bytes, s)
+               : pairwise ? launch_sweep_t<MC, false, false, true, 0, false, true>(p, blocks, threads, lds_bytes, s)
+                          : launch_sweep_t<MC, false, false, false, 0, false, true>(p, blocks, threads, lds_bytes, s);
+    if (p.sys_order) // systematic scan: direct back-end, tables from global memory, chain state in LDS
+        return (p.log || per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, 2>(p, blocks, threads, lds_bytes, s);
+    if (p.log) return (per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, 0, true>(p, blocks, threads, lds_bytes, s);
+    if (per_chain) return tab_lds ? launch_sweep_t<MC, false, true, false, 1>(p, blocks, threads, lds_bytes, s)
+                                  : launch_sweep_t<MC, false, false, false, 1>(p, blocks, threads, lds_bytes, s);
     if (cpt) return tab_lds ? launch_sweep_t<MC, true, true, false>(p, blocks, threads, lds_bytes, s)
                             : launch_sweep_t<MC, true, false, false>(p, blocks, threads, lds_bytes, s);
     if (pairwise) return tab_lds ? launch_sweep_t<MC, false, true, true>(p, blocks, threads, lds_bytes, s)

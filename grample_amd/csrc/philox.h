@@ -27,6 +27,7 @@ enum : uint32_t {
     DOM_INIT = 3,     // per chain, per variable: start state
     DOM_COLLAPSE = 4, // per variant, per try: Collapse(-1) selection
     DOM_SCAN_CHAIN = 5, // per chain, per 4 steps: which variable to update (strict mode GR_FLAG_SCAN_PER_CHAIN)
+    DOM_DRAW_SYS = 6,   // systematic scan (GR_FLAG_SCAN_SYSTEMATIC): per chain, per POSITION in the sweep order, per 4 sweeps: the draws
 };
 
 struct u32x4 {
@@ -60,6 +61,14 @@ GR_HD u32x4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, ui
         k1 += PHILOX_W1;
     }
     return u32x4{c0, c1, c2, c3};
+}
+
+// The draws of the systematic scan: update `pos` of sweep `sweep` of chain `gchain` uses word (sweep & 3) of this call, so that
+// a lane that owns one position of the order (k_sweep_chroma) needs one Philox call per 4 sweeps and no exchange with other
+// lanes.  Counter: (sweep / 4 [low 32 bits], pos [20 bits] | sweep / 4 [bits 32..43] << 20, chain [low 32], domain | chain [high] << 4).
+GR_HD u32x4 philox_sys_draw(uint64_t sweep, uint32_t pos, uint64_t gchain, uint32_t k0, uint32_t k1) {
+    const uint64_t sq = sweep >> 2;
+    return philox4x32_10((uint32_t)sq, pos | ((uint32_t)(sq >> 32) << 20), (uint32_t)gchain, DOM_DRAW_SYS + ((uint32_t)(gchain >> 32) << 4), k0, k1);
 }
 
 // uniform integer in [0, n) from a 32-bit word: floor(u * n / 2^32).  The

@@ -150,6 +150,10 @@ struct gr_sampler {
     bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
     bool par_lean = false;            // ... with the lean LDS layout: records always from global memory (large models)
     uint32_t par_stride = 80;         // ... bytes between the LDS state rows of consecutive variables
+    bool sysscan = false;             // GR_FLAG_SCAN_SYSTEMATIC
+    bool chroma = false;              // ... on k_sweep_chroma (binary memoised, few lane slots); else the generic kernel's systematic mode
+    uint32_t chroma_row = 0, chroma_tab_off = 0, chroma_hist_off = 0, chroma_lds = 0, chroma_nslot = 0, sys_n_free = 0, chroma_wpb = 4;
+    DevBuf<uint32_t> d_sys_order, d_sys_pos, d_chroma_slots, d_recs_chroma;
     bool no_wide = false;             // fast_form 3: every automatic choice, but never the wide form (measurements)
     bool wide_ok = false;             // ... the 8 / 16 lanes-per-chain form (k_sweep_wide) may take its place when wavefronts are what a launch lacks
     uint32_t lpc_last = 4;            // lanes per chain of the last step-parallel launch (gr_sampler_get_info)
@@ -245,11 +249,45 @@ void gr_sampler::configure() {
         wide_ok = fast && par && !strict_fast && par_packed && rec_bytes < (1ull << 26) && !o.block_threads &&
                   (o.fast_form == 0 || o.fast_form == 2 || o.fast_form >= 6) && par_rec_off <= kLdsBudget;
     }
+    // systematic scan: the chromatic kernel when every group is binary + memoised with at most 4 lane slots (colour classes cut
+    // into chunks of 64 variables) and 8 neighbours, all groups sweep the same number of variables, and the threshold pool fits
+    // LDS next to the chains' rows; otherwise (and for the sweeps' heads and tails) the generic kernel's systematic mode
+    chroma = false;
+    if (sysscan) {
+        if (stg) throw Error(GR_E_UNSUPPORTED, "GR_FLAG_SCAN_SYSTEMATIC needs the chain state in LDS (model too large, or GR_FLAG_STATE_GLOBAL)");
+        sys_n_free = (uint32_t)image[0].free_vars.size();
+        bool ok = fast && cpt && fast_slots <= 8 && n_vars < 65536 && !(o.flags & (GR_FLAG_DIRECT | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE)) &&
+                  (o.n_chains % 16u) == 0 && o.fast_form != 1;
+        uint32_t nslot = 0, cpt_max = 0;
+        for (const auto &im : image) {
+            uint32_t ns = 0;
+            for (size_t c = 0; c + 1 < im.color_off.size(); ++c) ns += (im.color_off[c + 1] - im.color_off[c] + 63u) / 64u;
+            nslot = std::max(nslot, ns);
+            cpt_max = std::max<uint32_t>(cpt_max, (im.cpt_words + 3u) & ~3u);
+            ok = ok && im.free_vars.size() == sys_n_free;
+            if (ok)
+                for (uint32_t v : im.free_vars) {
+                    const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
+                    const uint32_t nn = (cp[0] >> 8) & 0xffu;
+                    for (uint32_t i = 0; i < nn; ++i) ok = ok && cp[4 + 2 * i] * 4u < 65536u;
+                }
+        }
+        chroma_nslot = nslot;
+        chroma_row = ((uint32_t)n_vars + 15u) & ~15u;
+        chroma_wpb = 16; // chains (= wavefronts) per block: 16 consecutive chains make the state transfers 16-byte segments of the
+                         // global rows, and every block stages its own copy of the threshold tables
+        if (const char *e = getenv("GR_DEV_CHROMA_WPB")) chroma_wpb = (uint32_t)atoi(e); // (measurements only)
+        if (chroma_wpb != 1 && chroma_wpb != 2 && chroma_wpb != 4 && chroma_wpb != 8 && chroma_wpb != 16) chroma_wpb = 16;
+        chroma_tab_off = chroma_wpb * chroma_row;
+        chroma_hist_off = chroma_tab_off + cpt_max * 4u;
+        chroma_lds = chroma_hist_off + 8u * sys_n_free;
+        chroma = ok && nslot <= 4 && chroma_lds <= kLdsBudget;
+    }
     // value-parallel direct form: every group pairwise, the direct path chosen, Card 9..16, whole 64-chain scan groups
     pw4 = false;
     bool all_pw = true;
     for (const auto &im : image) all_pw = all_pw && im.pairwise;
-    if (all_pw && !fast && !cpt && !stg && max_card > 8 && max_card <= 16 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE)) &&
+    if (all_pw && !fast && !cpt && !stg && max_card > 8 && max_card <= 16 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE | GR_FLAG_SCAN_SYSTEMATIC)) &&
         o.fast_form != 1 && (o.n_chains % 64u) == 0 && (o.n_variants == 1 || cpv % 64u == 0) && !o.block_threads) {
         pw4_hist_off = ((uint32_t)n_vars * 64u + 15u) & ~15u;
         pw4_lds = pw4_hist_off + 4u * (uint32_t)H * 4u;
@@ -265,7 +303,7 @@ void gr_sampler::configure() {
     // evidence 3.5e10 there, 9.3e10 here), unless they are so small that most quads are one dependency chain (sample.uai)
     uint32_t nfree_min = 0xffffffffu;
     for (const auto &im : image) nfree_min = std::min<uint32_t>(nfree_min, (uint32_t)im.free_vars.size());
-    if (!fast && (!cpt || nfree_min >= 16u) && !stg && !pw4 && max_card <= 4 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE | GR_FLAG_DIRECT)) &&
+    if (!fast && (!cpt || nfree_min >= 16u) && !stg && !pw4 && max_card <= 4 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE | GR_FLAG_DIRECT | GR_FLAG_SCAN_SYSTEMATIC)) &&
         o.fast_form != 1 && (o.n_chains % 64u) == 0 && (o.n_variants == 1 || cpv % 64u == 0) && !o.block_threads &&
         (uint64_t)n_vars * kParStateStride < 65536u && H < 16384) {
         bool ok = true;
@@ -300,6 +338,8 @@ void gr_sampler::configure() {
 
 void gr_sampler::configure_paths() {
     strict_fast = false;
+    sysscan = (o.flags & GR_FLAG_SCAN_SYSTEMATIC) != 0;
+    if (sysscan && (o.flags & GR_FLAG_SCAN_PER_CHAIN)) throw Error(GR_E_INVALID, "GR_FLAG_SCAN_SYSTEMATIC and GR_FLAG_SCAN_PER_CHAIN exclude each other");
     if ((o.flags & GR_FLAG_SCAN_PER_CHAIN) && !(o.flags & GR_FLAG_DIRECT)) {
         // strict mode first tries the memoised tables in the 4-lane form's LDS layout (k_sweep_strict)
         try {
@@ -617,6 +657,37 @@ void gr_sampler::rebuild() {
         plan_steps = (uint32_t)std::max<uint64_t>(ps, 64);
         d_plan.alloc((size_t)waves * plan_steps + 64);
     }
+    if (sysscan) {
+        std::vector<uint32_t> order, pos, slots, recs;
+        for (uint32_t g = 0; g < n_build; ++g) {
+            const VariantImage &im = image[g];
+            order.insert(order.end(), im.sys_order.begin(), im.sys_order.end()); // (same pool layout as free_vars: free_base)
+            std::vector<uint32_t> where((size_t)n_vars, 0);
+            for (size_t i = 0; i < im.sys_order.size(); ++i) where[im.sys_order[i]] = (uint32_t)i;
+            std::vector<uint32_t> rank((size_t)n_vars, 0);
+            for (size_t i = 0; i < im.free_vars.size(); ++i) { pos.push_back(where[im.free_vars[i]]); rank[im.free_vars[i]] = (uint32_t)i; }
+            if (!chroma) continue;
+            h_variants[g].csl_base = (uint32_t)(slots.size() / 64u);
+            for (size_t c = 0; c + 1 < im.color_off.size(); ++c)
+                for (uint32_t b = im.color_off[c]; b < im.color_off[c + 1]; b += 64u)
+                    for (uint32_t l = 0; l < 64u; ++l) slots.push_back(b + l < im.color_off[c + 1] ? rank[im.sys_order[b + l]] : 0xffffffffu);
+            h_variants[g].csl_n = (uint32_t)(slots.size() / 64u) - h_variants[g].csl_base;
+            for (uint32_t v : im.free_vars) { // records in free-list order (rec_base), 16 words each
+                const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
+                const uint32_t nn = (cp[0] >> 8) & 0xffu;
+                uint32_t r[16] = {0};
+                r[0] = v; r[1] = cp[1]; r[2] = cp[2] * 4u; r[3] = nn;
+                for (uint32_t i = 0; i < 12u; ++i) r[4 + i] = (i < nn ? cp[3 + 2 * i] : v) | ((i < nn ? cp[4 + 2 * i] * 4u : 0u) << 16);
+                recs.insert(recs.end(), r, r + 16);
+            }
+        }
+        order.resize(order.size() + 4, 0); pos.resize(pos.size() + 4, 0); slots.resize(slots.size() + 64, 0xffffffffu); recs.resize(recs.size() + 16, 0);
+        d_sys_order.upload(order, stream, stage);
+        d_sys_pos.upload(pos, stream, stage);
+        d_chroma_slots.upload(slots, stream, stage);
+        d_recs_chroma.upload(recs, stream, stage);
+        d_variants.upload(h_variants, stream, stage); // now with the lane slots
+    }
     if (dir4) {
         // step headers + factor entries of the direct 4-lane form, from the generic programs (compiled_model.hpp)
         std::vector<uint32_t> hdr, ent;
@@ -748,7 +819,45 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         T = 256; blocks = (act + 255) / 256;
         generic(n_total);
     };
-    if (dir4 && !fast) {
+    if (sysscan) {
+        // systematic scan: whole sweeps from a sweep boundary on the chromatic kernel, everything else (and every model that
+        // kernel does not take) on the generic kernel's systematic mode -- same order, same draws, same thresholds
+        auto sys_generic = [&](uint64_t n_total) {
+            struct Restore { uint32_t &t, &b, kt, kb; ~Restore() { t = kt; b = kb; } } restore{T, blocks, T, blocks};
+            if (T > 256) { T = 256; blocks = (act + 255) / 256; }
+            uint64_t left = n_total;
+            while (left) {
+                const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
+                p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
+                p.n_steps = n;
+                p.sys_order = d_sys_order.p;
+                hip_check(launch_sweep(p, max_card, false, false, false, false, false, (act + T - 1) / T, T, lds, stream), "k_sweep (systematic) launch");
+                step += n; left -= n; launches_last++;
+            }
+        };
+        uint64_t left = updates;
+        if (chroma) {
+            FastParams f{};
+            f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p; f.cpt = d_cpt.p;
+            f.state = d_state.p; f.counts = d_counts.p;
+            f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = act; f.pitch = pitch; f.chains_per_variant = cpv;
+            f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
+            f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi; f.counting = p.counting;
+            f.chroma_slots = d_chroma_slots.p; f.recs_chroma = d_recs_chroma.p; f.sys_pos = d_sys_pos.p;
+            f.chroma_row = chroma_row; f.chroma_tab_off = chroma_tab_off; f.chroma_wpb = chroma_wpb; f.chroma_hist_off = chroma_hist_off;
+            const uint64_t head = std::min<uint64_t>(left, (sys_n_free - step % sys_n_free) % sys_n_free);
+            if (head) { sys_generic(head); left -= head; }
+            while (left >= sys_n_free) {
+                const uint64_t max_sweeps = std::max<uint64_t>(1, kMaxStepsPerLaunch / sys_n_free);
+                const uint32_t n = (uint32_t)(std::min<uint64_t>(left / sys_n_free, max_sweeps) * sys_n_free);
+                f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
+                f.n_steps = n;
+                hip_check(launch_sweep_chroma(f, (int)chroma_nslot, fast_slots, act / chroma_wpb, chroma_lds, stream), "k_sweep_chroma launch");
+                step += n; left -= n; launches_last++;
+            }
+        }
+        if (left) sys_generic(left);
+    } else if (dir4 && !fast) {
         // quad-unaligned head and tail go through the generic kernel (bit-identical streams), the rest in launches of
         // k_scan_plan + k_sweep_dir4 (16 steps per inner iteration)
         FastParams f{};
@@ -911,6 +1020,12 @@ void gr_sampler::burn_groups(uint32_t first, uint32_t last, uint32_t updates) {
     p.n_steps = updates; p.counting = 0; p.sequential = 0;
     p.lds_hist_off = lds_hist_off; p.lds_tab_off = lds_tab_off;
     const uint32_t t = std::min(T, 256u);
+    if (sysscan) {
+        p.sys_order = d_sys_order.p;
+        hip_check(launch_sweep(p, max_card, false, false, false, false, false, ((last - first) * cpv + t - 1) / t, t, lds, stream), "k_sweep launch (group burn-in)");
+        sync();
+        return;
+    }
     hip_check(launch_sweep(p, max_card, cpt && !strict_fast, tab_lds && !strict_fast, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, stg, ((last - first) * cpv + t - 1) / t, t, lds, stream),
               "k_sweep launch (group burn-in)");
     sync();
@@ -1556,6 +1671,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         if (!s) throw Error(GR_E_INVALID, "null sampler");
         if (cw < 2) throw Error(GR_E_INVALID, "ConvergenceWindow must be >= 2");
         if (s->o.flags & GR_FLAG_SCAN_PER_CHAIN) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain is not available in strict per-chain scan mode");
+        if (s->o.flags & GR_FLAG_SCAN_SYSTEMATIC) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain is the random scan's stopping rule (chain.go:184-215): use gr_advance_window with GR_FLAG_SCAN_SYSTEMATIC");
         s->use();
         if (s->dirty) s->rebuild();
         if (s->stg) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain needs the chain state in LDS (model too large, or GR_FLAG_STATE_GLOBAL): use gr_advance_window");
@@ -1871,7 +1987,7 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         out->block_threads = s->T; out->n_blocks = s->blocks;
         out->lds_bytes = s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->dir4 ? s->dir_lds : s->lds; // of the kernel that actually runs
         if (s->fast && s->par) { out->block_threads = s->strict_fast ? s->T : 64u * s->lpc_last; out->n_blocks = s->active_chains() / 64u; } // (64 x lanes per chain of the last launch)
-        out->path = s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
+        out->path = s->sysscan ? (s->chroma ? 9u : 0u) : s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

@@ -1,0 +1,173 @@
+// K1, chromatic form (GR_FLAG_SCAN_SYSTEMATIC): systematic scan over the colour classes of the factor graph,
+// all variables of a class updated side by side.
+//
+// The reference draws a random variable per update (sampler.go:135-174); a chain's updates are then sequential by construction
+// and the kernels of sweep_bin.hip find their parallelism ACROSS chains (and across a few commuting steps of one chain).  Under
+// the systematic scan the order is fixed -- colour 0's variables, colour 1's, ... -- and the variables of one colour share no
+// factor, so a whole class can be resampled at once: ONE WAVEFRONT PER CHAIN, one lane per variable of the class.  A lane slot
+// = (colour class, 64-variable chunk of it); each lane owns the same variable in every sweep, so everything about it -- its
+// row offsets, multipliers, threshold-table address, its place in the histogram -- is loaded ONCE into registers: no scan
+// stream, no plan, no records per step, no dependency levels, no histogram atomics (a lane counts its own variable's ones in
+// a register).  4 096 chains are 4 096 wavefronts: the chip is full from BASELINE config 1 up.
+//   chain state   lds[wave * row + var]  (one row of n_vars bytes per chain; the lanes of a class read distinct bytes)
+//   tables        memoised thresholds (k_build_cpt), staged in LDS per block
+//   draws         philox_sys_draw(sweep, position in the order, chain): word (sweep & 3) -- one Philox call per lane and 4 sweeps
+//   classes       one wavefront executes its LDS operations in order, so class k + 1 sees class k's writes without a barrier
+//                 (a wavefront-scope fence keeps the compiler from moving loads across the stores)
+// Same thresholds, same draw stream and same order as the generic kernel's systematic mode (k_sweep<.., SCAN 2>): bit-identical
+// results (tests/test_gpu_systematic.py); launches that do not start or end on a sweep boundary go through that kernel.
+// Limits of this form: every selectable variable binary and memoised, at most NSLOT lane slots (2 or 4) and 8 neighbours.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+#include "kernels.h"
+#include "philox.h"
+
+namespace gr {
+
+namespace {
+typedef __attribute__((address_space(3))) uint32_t lds_u32c_t;
+typedef __attribute__((address_space(3))) unsigned char lds_u8c_t;
+__device__ __forceinline__ uint32_t lds_addr_c(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p; }
+__device__ __forceinline__ uint32_t mad_u16_hi_c(const uint32_t w, const uint32_t b, const uint32_t c) {
+    uint32_t d;
+    asm("v_mad_u32_u16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(w), "v"(b), "v"(c));
+    return d;
+}
+} // namespace
+
+// chroma record (64 bytes per entry of the free list): w0 = the variable's byte inside a chain's row, w1 = its histogram offset
+// (model layout), w2 = byte offset of its threshold table inside the staged pool, w3 = neighbours, w[4 + i] = neighbour's byte
+// inside the row | (4 * multiplier) << 16 (unused slots: the variable's own byte, multiplier 0)
+template <int NSLOT, int SLOTS, bool COUNT>
+__global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nthr = blockDim.x;
+    const uint32_t chain = blockIdx.x * p.chroma_wpb + wave;
+    const uint32_t variant = (blockIdx.x * p.chroma_wpb) / p.chains_per_variant; // blocks never straddle groups
+    const VariantDesc vd = p.variants[variant];
+    {   // stage the threshold tables and this wavefront's chain
+        const uint32_t n4 = (vd.cpt_len + 3u) >> 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + p.chroma_tab_off);
+        for (uint32_t i = tid; i < n4; i += nthr) dst[i] = src[i];
+        // the block's chains are consecutive: a lane group of chroma_wpb lanes reads one variable's bytes of all of them (one
+        // segment of the global row) -- per lane and variable it would be one 64-byte line per byte
+        const uint32_t wpb = p.chroma_wpb, chain0 = blockIdx.x * wpb;
+        for (uint32_t i = tid; i < p.n_vars * wpb; i += nthr) {
+            const uint32_t v = i / wpb, c = i % wpb;
+            lds[c * p.chroma_row + v] = p.state[(size_t)v * p.pitch + chain0 + c];
+        }
+    }
+    __syncthreads();
+    const uint32_t row = lds_addr_c(lds) + wave * p.chroma_row;          // absolute LDS address of my chain's row
+    const uint32_t tab = lds_addr_c(lds) + p.chroma_tab_off;
+    const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
+    const uint64_t step0 = ((uint64_t)p.step0_hi << 32) | p.step0_lo;
+    const uint64_t sweep0 = step0 / vd.n_free;                           // (the host launches whole sweeps from a sweep boundary)
+    const uint32_t n_sweeps = p.n_steps / vd.n_free;
+
+    // my variable of every lane slot: loaded once
+    bool on[NSLOT];
+    uint32_t own[NSLOT], tbl[NSLOT], nb[NSLOT][SLOTS], mw[NSLOT][SLOTS], pos[NSLOT], rk[NSLOT], ones[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        const uint32_t k = (uint32_t)s < vd.csl_n ? p.chroma_slots[(size_t)(vd.csl_base + s) * 64u + lane] : 0xffffffffu;
+        on[s] = k != 0xffffffffu;
+        const uint32_t kk = on[s] ? k : 0u;
+        const uint32_t *r = p.recs_chroma + (size_t)(vd.rec_base + kk) * 16u;
+        own[s] = row + r[0];
+        rk[s] = kk;
+        tbl[s] = tab + r[2];
+        pos[s] = p.sys_pos[vd.free_base + kk];
+        ones[s] = 0;
+#pragma unroll
+        for (int i = 0; i < SLOTS; ++i) {
+            const uint32_t w = r[4 + i];
+            nb[s][i] = row + (w & 0xffffu);
+            mw[s][i] = w; // the multiplier sits in the high half: V_MAD_U32_U16 op_sel takes it from there
+        }
+    }
+
+    for (uint64_t sq = sweep0 >> 2; (sq << 2) < sweep0 + n_sweeps; ++sq) {
+        uint32_t U[NSLOT][4];
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            const u32x4 d = philox_sys_draw(sq << 2, pos[s], gchain, p.seed_lo, p.seed_hi);
+            U[s][0] = d.x; U[s][1] = d.y; U[s][2] = d.z; U[s][3] = d.w;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t sweep = (sq << 2) + (uint64_t)w;
+            if (sweep < sweep0 || sweep >= sweep0 + n_sweeps) continue; // (uniform)
+#pragma unroll
+            for (int s = 0; s < NSLOT; ++s) {
+                if ((uint32_t)s >= vd.csl_n) break; // (uniform)
+                // the class before this one has committed: in-order LDS in hardware, the fence for the compiler
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                uint32_t x[SLOTS];
+#pragma unroll
+                for (int i = 0; i < SLOTS; ++i) x[i] = (uint32_t)*(lds_u8c_t *)(uintptr_t)nb[s][i];
+                uint32_t a = tbl[s];
+#pragma unroll
+                for (int i = SLOTS - 1; i >= 0; --i) a = mad_u16_hi_c(mw[s][i], x[i], a);
+                const uint32_t T = *(lds_u32c_t *)(uintptr_t)a;
+                const bool val = U[s][w] >= T;
+                if (on[s]) {
+                    *(lds_u8c_t *)(uintptr_t)own[s] = val ? (unsigned char)1 : (unsigned char)0;
+                    if constexpr (COUNT) ones[s] += val ? 1u : 0u;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t wpb = p.chroma_wpb, chain0 = blockIdx.x * wpb;
+        for (uint32_t i = tid; i < p.n_vars * wpb; i += nthr) {
+            const uint32_t v = i / wpb, c = i % wpb;
+            p.state[(size_t)v * p.pitch + chain0 + c] = lds[c * p.chroma_row + v];
+        }
+    }
+    if constexpr (COUNT) {
+        // Every chain of the block counted its own variables' ones in registers; the block adds them up in LDS (histogram indexed
+        // by rank in the free list: (zeros, ones) pairs) and sends ONE atomic per counter to the global histogram -- per lane and
+        // chain it was 52 M atomics on 200 addresses for 262 144 chains, three times the sweeps' own time.
+        uint32_t *h = reinterpret_cast<uint32_t *>(lds + p.chroma_hist_off);
+        for (uint32_t i = tid; i < 2u * vd.n_free; i += nthr) h[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s)
+            if (on[s] && (uint32_t)s < vd.csl_n) {
+                atomicAdd(&h[2u * rk[s] + 1u], ones[s]);
+                atomicAdd(&h[2u * rk[s]], n_sweeps - ones[s]);
+            }
+        __syncthreads();
+        unsigned long long *gc = p.counts + (size_t)variant * p.H;
+        for (uint32_t i = tid; i < vd.n_free; i += nthr) {
+            const uint32_t v = p.free_vars[vd.free_base + i];
+            const uint32_t ho = p.cprogs[vd.cprog_base + p.cprog_off[vd.cprogoff_base + v] + 1u];
+            if (h[2u * i]) atomicAdd(&gc[ho], (unsigned long long)h[2u * i]);
+            if (h[2u * i + 1u]) atomicAdd(&gc[ho + 1u], (unsigned long long)h[2u * i + 1u]);
+        }
+    }
+}
+
+template <int NSLOT, int SLOTS>
+static hipError_t launch_chroma_t(const FastParams &p, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64u * p.chroma_wpb), lds, s, p);
+        return hipGetLastError();
+    };
+    return p.counting ? go(&k_sweep_chroma<NSLOT, SLOTS, true>) : go(&k_sweep_chroma<NSLOT, SLOTS, false>);
+}
+
+hipError_t launch_sweep_chroma(const FastParams &p, int n_lane_slots, int slots, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    if (n_lane_slots > 4 || slots > 8) return hipErrorInvalidValue;
+    if (n_lane_slots <= 2) return slots <= 4 ? launch_chroma_t<2, 4>(p, blocks, lds, s) : launch_chroma_t<2, 8>(p, blocks, lds, s);
+    return slots <= 4 ? launch_chroma_t<4, 4>(p, blocks, lds, s) : launch_chroma_t<4, 8>(p, blocks, lds, s);
+}
+
+} // namespace gr

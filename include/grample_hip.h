@@ -111,6 +111,16 @@ int gr_error_suite(int32_t n_vars, const int32_t *card, const int32_t *fixed1, c
                                             staging it in LDS: chosen automatically for models whose state does not fit LDS
                                             (n_vars * 64 B > 160 KiB per wavefront); as a flag it forces that kernel (cross-checks) */
 
+#define GR_FLAG_SCAN_SYSTEMATIC (1u << 5) /* systematic (chromatic) scan instead of the reference's random scan (sampler.go:135-174): the selectable
+                                            variables are coloured so that variables of one colour share no factor; update t of a chain resamples
+                                            variable order[t mod n] -- colour class by colour class, ascending id inside a class -- so updates
+                                            per chain still count single-variable updates and n of them are one sweep.  The stationary law is the
+                                            model's, like the random scan's; the chain's law is NOT the reference's (off by default).
+                                            Binary memoisable models with small blankets run k_sweep_chroma: one wavefront per chain, one lane per
+                                            variable of a colour class, all of a class updated side by side -- full occupancy from 4 096 chains up.
+                                            Not combinable with GR_FLAG_SCAN_PER_CHAIN; gr_advance_chain / gr_advance_window keep working through
+                                            gr_advance_window only (the stopping rule of AdvanceChain is a property of the random scan). */
+
 typedef struct gr_sampler_opts {
     uint32_t struct_size;    /* = sizeof(gr_sampler_opts) */
     uint32_t n_chains;       /* chains on this device */
@@ -232,6 +242,7 @@ typedef struct gr_sampler_info {
     uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path), 3 = same, 4 lanes per chain, 5 = strict per-chain scan on memoised tables,
                                6 = direct conditional, value-parallel (4 lanes per chain, pairwise models with 8 < Card <= 16);
                                8 = direct conditional, step-parallel (4 lanes per chain: Card <= 4, arity <= 4, blankets too large to memoise);
+                               9 = systematic (chromatic) scan on memoised tables, one wavefront per chain (GR_FLAG_SCAN_SYSTEMATIC);
                                + 16 when the chain state stays in global memory (paths 0 and 1 only) */
     uint32_t max_card;
     uint32_t tables_in_lds; /* threshold / view tables: 1 = staged in LDS, 0 = read from global memory, 2 = split (4-lane memoised form:

@@ -10,7 +10,7 @@ import numpy as np
 
 M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 W0, W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
-DOM_DRAW, DOM_SCAN, DOM_INIT, DOM_SCAN_CHAIN = 1, 2, 3, 5
+DOM_DRAW, DOM_SCAN, DOM_INIT, DOM_SCAN_CHAIN, DOM_DRAW_SYS = 1, 2, 3, 5, 6
 
 
 def philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -51,14 +51,36 @@ def init_state(card, fixed, n_chains, seed, chain_offset=0, epoch=0):
     return st
 
 
+def systematic_order(card, fixed, scopes, collapsed=()):
+    """The sweep order of GR_FLAG_SCAN_SYSTEMATIC (compiled_model.cpp): greedy colouring of the selectable variables in ascending
+    id (smallest colour no already-coloured neighbour uses; neighbours = variables sharing a factor), then by (colour, id)."""
+    n = len(card)
+    free = [v for v in range(n) if fixed[v] < 0 and v not in collapsed]
+    nb = [set() for _ in range(n)]
+    for sc in scopes:
+        for a in sc:
+            for b in sc:
+                if a != b:
+                    nb[a].add(b)
+    color = {}
+    for v in free:
+        used = {color[u] for u in nb[v] if u in color}
+        c = 0
+        while c in used:
+            c += 1
+        color[v] = c
+    return sorted(free, key=lambda v: (color[v], v)), color
+
+
 class Emulator:
     """Replays the sweep kernel for n_chains chains of one chain group.
 
     thresholds(v, state_column) -> uint64 array of Card-1 cumulative thresholds.
     """
 
-    def __init__(self, card, fixed, free_vars, thresholds, n_chains, seed, chain_offset=0, per_chain=False):
+    def __init__(self, card, fixed, free_vars, thresholds, n_chains, seed, chain_offset=0, per_chain=False, systematic=None):
         self.per_chain = per_chain
+        self.systematic = systematic  # the sweep order (list of variables) of GR_FLAG_SCAN_SYSTEMATIC, or None
         self.card, self.fixed = list(card), list(fixed)
         self.free = list(free_vars)
         self.thr = thresholds
@@ -75,6 +97,26 @@ class Emulator:
         g = np.arange(self.n_chains, dtype=np.uint64) + np.uint64(self.off)
         wave = (g >> np.uint64(6)).astype(np.uint32)
         for s in range(self.step, self.step + n_steps):
+            if self.systematic is not None:  # update s resamples order[s mod n] with word (sweep & 3) of philox_sys_draw(sweep, pos, chain)
+                nfree = len(self.systematic)
+                sweep, pos = divmod(s, nfree)
+                sq = sweep >> 2
+                dr = philox4x32_10(np.full(self.n_chains, sq & 0xFFFFFFFF, dtype=np.uint32), np.full(self.n_chains, pos | ((sq >> 32) << 20), dtype=np.uint32),
+                                   g.astype(np.uint32), np.uint32(DOM_DRAW_SYS) + ((g >> np.uint64(32)).astype(np.uint32) << np.uint32(4)), k0, k1)[sweep & 3]
+                v = self.systematic[pos]
+                vals = np.zeros(self.n_chains, dtype=np.int64)
+                for c in range(self.n_chains):
+                    if self.frozen[c]:
+                        continue
+                    T = self.thr(v, self.state[:, c])
+                    val = int(np.sum(np.uint64(dr[c]) >= T))
+                    self.state[v, c] = val
+                    vals[c] = val
+                    if counting:
+                        self.counts[self.hoff[v] + val] += np.uint64(1)
+                if counting and self.record is not None:
+                    self.record.append((np.full(self.n_chains, v), vals, ~self.frozen))
+                continue
             q, j = s >> 2, s & 3
             ql, qh = np.uint32(q & 0xFFFFFFFF), np.uint32(q >> 32)
             if self.per_chain:  # strict mode: the scan stream is keyed by the chain, not by its 64-chain group

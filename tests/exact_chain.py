@@ -18,7 +18,10 @@ import itertools
 import numpy as np
 
 
-def expected_histogram(oracle, pm):
+def expected_histogram(oracle, pm, order=None):
+    """order = None: the reference's random scan.  order = list of the selectable variables: the systematic scan that
+    resamples them one after the other in that order (GR_FLAG_SCAN_SYSTEMATIC): stationary law of a whole sweep, then the law the
+    chain has when it reaches each position of the sweep."""
     L = oracle.lib()
     om = oracle.Model.from_parsed(pm)
     gen = L.orc_gen_new(1)
@@ -45,22 +48,46 @@ def expected_histogram(oracle, pm):
                 t = list(s)
                 t[v] = val
                 P[i, index[tuple(t)]] += p[val] / len(free)
-    # stationary law: left eigenvector for eigenvalue 1 (solve (P^T - I) pi = 0, sum pi = 1)
-    A = np.vstack([P.T - np.eye(S), np.ones((1, S))])
-    b = np.zeros(S + 1)
-    b[-1] = 1.0
-    pi = np.linalg.lstsq(A, b, rcond=None)[0]
-    pi = np.clip(pi, 0, None)
-    pi /= pi.sum()
-    out = []
-    for v in range(n):
-        if fixed[v] >= 0:
-            out.append(None)
-            continue
-        f = np.zeros(card[v])
-        for i in range(S):
-            f += pi[i] * cond[(i, v)]
-        out.append(f)
+    def stationary(P):  # left eigenvector for eigenvalue 1 (solve (P^T - I) pi = 0, sum pi = 1)
+        A = np.vstack([P.T - np.eye(S), np.ones((1, S))])
+        b = np.zeros(S + 1)
+        b[-1] = 1.0
+        pi = np.linalg.lstsq(A, b, rcond=None)[0]
+        pi = np.clip(pi, 0, None)
+        return pi / pi.sum()
+    if order is None:
+        pi = stationary(P)
+        out = []
+        for v in range(n):
+            if fixed[v] >= 0:
+                out.append(None)
+                continue
+            f = np.zeros(card[v])
+            for i in range(S):
+                f += pi[i] * cond[(i, v)]
+            out.append(f)
+    else:
+        assert sorted(order) == free
+        K = {}
+        for v in free:  # the kernel of one update of v
+            Kv = np.zeros((S, S))
+            for i, s in enumerate(states):
+                for val in range(card[v]):
+                    t = list(s)
+                    t[v] = val
+                    Kv[i, index[tuple(t)]] += cond[(i, v)][val]
+            K[v] = Kv
+        Psweep = np.eye(S)
+        for v in order:
+            Psweep = Psweep @ K[v]
+        pi = stationary(Psweep)
+        out = [None] * n
+        for v in order:
+            f = np.zeros(card[v])
+            for i in range(S):
+                f += pi[i] * cond[(i, v)]
+            out[v] = f
+            pi = pi @ K[v]
     L.orc_simple_free(samp)
     L.orc_gen_free(gen)
     return out

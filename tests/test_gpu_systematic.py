@@ -1,0 +1,145 @@
+"""GR_FLAG_SCAN_SYSTEMATIC ("chromatic/systematic scan option"), run with -m gpu.
+
+The systematic scan replaces the reference's variable selection (UniformSampler.VarSample, sampler/sampler.go:135-174) by a
+fixed order -- colour class by colour class of a greedy colouring of the factor graph -- so its chain law is NOT the
+reference's; what it shares with it is every conditional (same thresholds as the random-scan kernels, checked against the oracle
+in test_gpu_parity.py) and therefore the stationary law.  Evidence here:
+  1. bit-for-bit replay by the numpy emulator (order, draw stream, counting), chromatic kernel and generic kernel alike;
+  2. the chromatic kernel (path 9) == the generic kernel's systematic mode, at sizes the emulator cannot reach;
+  3. exact long-run histogram of the systematic chain built from ORACLE conditionals (tests/exact_chain.py) on tiny models;
+  4. stationary marginals vs the ORACLE's random-scan runs (two-sample z) on models that mix.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import grample_amd as g
+from tests import exact_chain, uai_py
+from tests.emulator import Emulator, systematic_order
+
+pytestmark = pytest.mark.gpu
+SYS = g.GR_FLAG_SCAN_SYSTEMATIC
+
+
+def _gm(pm):
+    return g.Model.from_arrays(pm.card, pm.scopes, pm.tables, pm.fixed)
+
+
+@pytest.mark.parametrize("name,ev,chains,burn,steps,flags,path", [
+    ("Grids_11.uai", False, 128, 13, 457, 0, 9),            # chromatic kernel; the launches start and end inside a sweep
+    ("Grids_11.uai", False, 64, 250, 230, g.GR_FLAG_DIRECT, 0),  # generic kernel, systematic mode
+    ("ObjectDetection_13.uai", False, 64, 7, 150, 0, 0),    # Card 16
+    ("Pedigree_11.uai", True, 64, 5, 700, 0, 0),            # evidence, Card 3, arity 4
+    ("grid3x3", False, 192, 3, 100, 0, 9),
+    ("mixed_evidence", False, 64, 2, 41, 0, 0),
+])
+def test_systematic_sweep_bitwise_vs_emulator(res_dir, name, ev, chains, burn, steps, flags, path):
+    from tests.test_gpu_parity import _thresholds_from_device
+    pm = uai_py.load(res_dir, name, ev) if name.endswith(".uai") else exact_chain.tiny_models()[name]
+    s = g.HIPChains(_gm(pm), chains, seed=321, chain_offset=64 * 7, flags=SYS | flags)
+    assert s.info()["path"] == path
+    order, color = systematic_order(pm.card, pm.fixed, pm.scopes)
+    for sc in pm.scopes:  # a proper colouring: no factor holds two selectable variables of one colour
+        cs = [color[v] for v in sc if v in color]
+        assert len(cs) == len(set(cs))
+    free = [v for v in range(len(pm.card)) if pm.fixed[v] < 0]
+    em = Emulator(pm.card, pm.fixed, free, _thresholds_from_device(s, pm.card), chains, 321, chain_offset=64 * 7, systematic=order)
+    s.BurnIn(burn); em.run(burn, False)
+    s.Advance(steps); em.run(steps, True)
+    s.Advance(len(order) + 1); em.run(len(order) + 1, True)
+    assert np.array_equal(s.counts()[0], em.counts)
+    for c in (0, 63, chains - 1):
+        assert np.array_equal(s.LastSample(c), em.state[:, c])
+    assert s.TotalSampleCount() == chains * (steps + len(order) + 1)
+
+
+@pytest.mark.parametrize("name,chains", [("Grids_13.uai", 4096), ("Grids_11.uai", 8192)])
+def test_chromatic_kernel_equals_generic_systematic(res_dir, name, chains):
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    out = []
+    for flags in (SYS, SYS | g.GR_FLAG_DIRECT):
+        s = g.HIPChains(m, chains, seed=5, flags=flags)
+        s.BurnIn(1234); s.Advance(100 * 37 + 11); s.Advance(100)
+        out.append((s.info()["path"], s.counts(), s.checkpoint()["states"]))
+    assert out[0][0] == 9 and out[1][0] == 0
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert int(out[0][1].sum()) == chains * (3711 + 100)
+    # every selectable variable is updated once per sweep: its counts sum to chains * sweeps (+ the partial sweeps' share)
+    per_var = out[0][1][0].reshape(100, 2).sum(axis=1)
+    assert per_var.min() >= chains * 38 and per_var.max() <= chains * 39
+
+
+@pytest.mark.parametrize("model", ["grid3x3", "mixed", "mixed_evidence"])
+def test_systematic_long_run_histogram_matches_exact_chain(oracle, model):
+    """the exact stationary behaviour of the systematic-scan chain whose single-variable kernels are the ORACLE's conditionals"""
+    pm = exact_chain.tiny_models()[model]
+    order, _ = systematic_order(pm.card, pm.fixed, pm.scopes)
+    exp = exact_chain.expected_histogram(oracle, pm, order=order)
+    s = g.HIPChains(_gm(pm), 4096, seed=99, flags=SYS)
+    s.BurnIn(200 * len(order)); s.Advance(600 * len(order))
+    cnt = s.counts()[0]
+    off = 0
+    for v, e in enumerate(exp):
+        c = cnt[off:off + pm.card[v]].astype(float)
+        off += pm.card[v]
+        if e is None:
+            assert c.sum() == 0
+            continue
+        n = c.sum()
+        assert n == 4096 * 600
+        tol = 6.0 * np.sqrt(np.maximum(e * (1 - e), 1e-6) / (n / 30.0)) + 1e-4
+        assert np.all(np.abs(c / n - e) <= tol), (model, v, c / n, e, tol)
+
+
+@pytest.mark.parametrize("name,burn_sw,upd_sw,per", [("ObjectDetection_13.uai", 20, 60, 8), ("CSP_13.uai", 20, 60, 8), ("one.uai", 0, 200, 8)])
+def test_systematic_marginals_match_oracle_random_scan(oracle, res_dir, name, burn_sw, upd_sw, per):
+    """Models that mix: the systematic chain's marginal estimates agree with the oracle's random-scan runs (same burn-in and update
+    counts; two-sample z over G groups as in test_marginals_match_oracle_runs), and with .MAR like they do."""
+    from tests.test_gpu_parity import _group_props
+    pm = uai_py.load(res_dir, name)
+    n = len(pm.card)
+    burn, upd = burn_sw * n, upd_sw * n
+    G = 32
+    s = g.HIPChains(g.Model.NewModelFromFile(os.path.join(res_dir, name)), G * 64, n_variants=G, seed=42, flags=SYS)
+    s.BurnIn(burn); s.Advance(upd)
+    pg = _group_props(s.counts(), pm.card)
+    om = oracle.Model.from_parsed(pm)
+    prior = np.concatenate([np.full(c, per / c) for c in pm.card])
+    co = np.zeros((G, sum(pm.card)))
+    for grp in range(G):
+        mo, _, _, tot = oracle.run_chains(om, 3000 + grp, per, burn, upd)
+        co[grp] = np.concatenate(mo) - prior
+    po = _group_props(np.rint(co), pm.card)
+    se = np.sqrt(po.var(axis=0, ddof=1) / G + pg.var(axis=0, ddof=1) / G)
+    z = (po.mean(axis=0) - pg.mean(axis=0)) / np.maximum(se, 2e-4)
+    assert np.max(np.abs(z)) <= 5.5 and np.mean(z ** 2) <= 2.0, (name, np.max(np.abs(z)), np.mean(z ** 2))
+    sol = uai_py.load_mar(res_dir, name)
+    split = lambda flat: g.split(flat, pm.card)  # noqa: E731
+    eo = g.NewErrorSuite(pm.card, sol, split(po.mean(axis=0) + 1e-12))
+    eg = g.NewErrorSuite(pm.card, sol, split(pg.mean(axis=0) + 1e-12))
+    assert abs(eo["MeanHellinger"] - eg["MeanHellinger"]) <= 0.02, (eo, eg)
+
+
+def test_systematic_flag_rules(res_dir):
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai"))
+    with pytest.raises(g.GrError):
+        g.HIPChains(m, 64, flags=SYS | g.GR_FLAG_SCAN_PER_CHAIN)
+    s = g.HIPChains(m, 256, flags=SYS, seed=1)
+    with pytest.raises(g.GrError):
+        s.AdvanceChain(4)  # the random scan's stopping rule
+    s.AdvanceWindow(400)  # the halves of the window in time
+    a, b, _ = s.window_halves()
+    assert a.sum() + b.sum() == 256 * 400
+    # the default (random scan) is untouched by the flag's existence: same counts as ever for the same seed
+    d1 = g.HIPChains(m, 256, seed=1); d1.Advance(400)
+    d2 = g.HIPChains(m, 256, seed=1, flags=SYS | g.GR_FLAG_DIRECT); d2.Advance(400)
+    assert not np.array_equal(d1.counts(), d2.counts())
+    # checkpoint / resume inside a sweep
+    t = g.HIPChains(m, 256, flags=SYS, seed=1)
+    t.BurnIn(37); t.Advance(255)
+    ck = t.checkpoint()
+    t.Advance(333)
+    u = g.HIPChains(m, 256, flags=SYS, seed=1)
+    u.restore(ck); u.Advance(333)
+    assert np.array_equal(t.counts(), u.counts())
