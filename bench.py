@@ -123,8 +123,9 @@ def oracle_probe(res_dir, g, name, sampler="simple", chains=256, burn_sweeps=20,
             "gpu_vs_cpu_oracle": {"mean_hellinger": e_x["MeanHellinger"], "max_hellinger": e_x["MaxHellinger"], "mean_abs_err": e_x["MeanMeanAbsError"]}}
 
 
-PATHS = {0: "direct (k_sweep)", 1: "memoised (k_sweep)", 2: "memoised+plan, chain per lane (k_sweep_bin)", 3: "memoised+plan, 4 lanes per chain (k_sweep_par4)",
-         5: "memoised, strict per-chain scan (k_sweep_strict)", 6: "direct, value-parallel (k_sweep_pw4)", 8: "direct, step-parallel (k_sweep_dir4)"}
+PATHS = {0: "direct (k_sweep)", 1: "memoised (k_sweep)", 2: "memoised+plan, chain per lane (k_sweep_bin)", 3: "memoised+plan, step-parallel (k_sweep_par4 / k_sweep_wide)",
+         5: "memoised, strict per-chain scan (k_sweep_strict)", 6: "direct, value-parallel (k_sweep_pw4)", 8: "direct, step-parallel (k_sweep_dir4)",
+         9: "memoised, systematic scan, one wavefront per chain (k_sweep_chroma)"}
 
 
 def other_configs(res_dir, g, device):
@@ -135,6 +136,7 @@ def other_configs(res_dir, g, device):
     specs = [  # title, model, sampler, chains, groups, burn-in sweeps, counted sweeps, probe kwargs
         ("configs[0] one.uai GibbsSimple, 1 chain, 1k iters", "one.uai", "simple", 1, 1, 0, 1000, dict(chains=64, burn_sweeps=0, sweeps=1000)),
         ("configs[1] Grids_11 GibbsSimple, 4096 chains", "Grids_11.uai", "simple", 4096, 1, 200, 4000, dict()),
+        ("configs[1'] the same with GR_FLAG_SCAN_SYSTEMATIC (chromatic scan; not the reference's chain law)", "Grids_11.uai", "systematic", 4096, 1, 200, 4000, None),
         ("configs[3] Segmentation_11 GibbsCollapsed, 32768 chains in 128 groups (one Collapse(-1) per group)", "Segmentation_11.uai", "collapsed", 32768, 128, 200, 1000,
          dict(sampler="collapsed", burn_sweeps=20, sweeps=100)),
         ("configs[4] ObjectDetection_13 GibbsSimple, per-GPU share: 32768 of 262144 chains", "ObjectDetection_13.uai", "simple", 32768, 1, 200, 600,
@@ -144,7 +146,7 @@ def other_configs(res_dir, g, device):
     for title, model, samp, chains, groups, burn, sweeps, pk in specs:
         m = g.Model.NewModelFromFile(os.path.join(res_dir, model))
         n = m.n_vars
-        s = g.HIPChains(m, chains, n_variants=groups, device=device, seed=42)
+        s = g.HIPChains(m, chains, n_variants=groups, device=device, seed=42, flags=g.GR_FLAG_SCAN_SYSTEMATIC if samp == "systematic" else 0)
         if samp == "collapsed":
             for k in range(groups):
                 s.Collapse(k, -1)
@@ -160,10 +162,11 @@ def other_configs(res_dir, g, device):
         rate = chains * sweeps * n / dt
         out.append({"config": title, "value": rate, "unit": "variable-updates/s", "timing": "wall clock around one gr_advance call of the counted phase",
                     "ms": dt * 1e3, "kernel_ms": info["kernel_ms_last"], "updates": chains * sweeps * n,
-                    "kernel": PATHS.get(info["path"] & 15, str(info["path"])), "collapsed_vars": int(np.sum(coll)),
+                    "kernel": PATHS.get(info["path"] & 15, str(info["path"])) + (f": {info['block_threads'] // 64} lanes per chain" if info["path"] == 3 else ""),
+                    "collapsed_vars": int(np.sum(coll)),
                     "hellinger_vs_MAR": {"mean": es["MeanHellinger"], "max": es["MaxHellinger"], "mean_abs_err": es["MeanMeanAbsError"]},
                     "effective_hbm_frac": ALGO_BYTES[model] * rate / 1e9 / HBM_PEAK_GBS,
-                    "oracle_probe": oracle_probe(res_dir, g, model, **pk)})
+                    "oracle_probe": oracle_probe(res_dir, g, model, **pk) if pk is not None else None})
         s.close()
     return out
 
@@ -319,7 +322,7 @@ def main():
                                    f"({upd_per_step} single-variable updates per chain) per step",
                        "chains_total": world * CHAINS_PER_GPU, "burnin_sweeps": BURNIN_SWEEPS,
                        "parallelism": f"chains sharded over {world} GPU(s), one RCCL all-reduce of 200 counters at the end",
-                       "kernel": {"path": PATHS.get(info["path"], str(info["path"]))}},
+                       "kernel": {"path": PATHS.get(info["path"], str(info["path"])), "lanes_per_chain": info["block_threads"] // 64 if info["path"] == 3 else None}},
             "hellinger_vs_MAR": {"mean": es["MeanHellinger"], "max": es["MaxHellinger"], "mean_abs_err": es["MeanMeanAbsError"]},
             "collective": {"backend": backend, "world": world if dist is not None else None, "allreduce_calls": n_allreduce[0],
                            "reduced_total": int(total_counts.sum()),
@@ -338,6 +341,22 @@ def main():
             out["strict_scan"] = {"value": CHAINS_PER_GPU * upd_per_step / (strict.info()["kernel_ms_last"] * 1e-3),
                                   "unit": "variable-updates/s", "note": "GR_FLAG_SCAN_PER_CHAIN, kernel time of one step"}
             strict.close()
+            # ... and with the systematic (chromatic) scan, GR_FLAG_SCAN_SYSTEMATIC: NOT the reference's chain law (a fixed update order
+            # instead of VarSample's random choice; same conditionals, same stationary law) -- the option SURVEY 8(f) N4 names
+            systematic = g.HIPChains(model, CHAINS_PER_GPU, device=local_rank, seed=42, flags=g.GR_FLAG_SCAN_SYSTEMATIC)
+            systematic.BurnIn(BURNIN_SWEEPS * n_vars)
+            systematic.Advance(upd_per_step)
+            t1 = time.perf_counter()
+            systematic.Advance(upd_per_step)
+            dts = time.perf_counter() - t1
+            ms, _ = g.MergeChains([systematic])
+            ess = g.NewErrorSuite(cards, sol, ms)
+            out["systematic_scan"] = {"value": CHAINS_PER_GPU * upd_per_step / dts, "unit": "variable-updates/s",
+                                      "kernel_value": CHAINS_PER_GPU * upd_per_step / (systematic.info()["kernel_ms_last"] * 1e-3),
+                                      "hellinger_vs_MAR": {"mean": ess["MeanHellinger"], "max": ess["MaxHellinger"]},
+                                      "note": "GR_FLAG_SCAN_SYSTEMATIC (k_sweep_chroma), wall clock of one step; off by default: the headline value above is the "
+                                              "reference's random scan"}
+            systematic.close()
             if not args.no_configs:
                 sampler.close()
                 out["configs"] = other_configs(res_dir, g, local_rank)
