@@ -133,6 +133,15 @@ func create(gm *C.gr_model, o *C.gr_sampler_opts) (*C.gr_sampler, error) {
 	return h, err
 }
 
+// ScanFlags is OR-ed into gr_sampler_opts.flags by the constructors below.  The default 0 is the reference's random scan
+// (one VarSample draw per 64-chain group and update); C.GR_FLAG_SCAN_PER_CHAIN gives every chain its own draw exactly like
+// UniformSampler.VarSample (sampler.go:135-174); C.GR_FLAG_SCAN_SYSTEMATIC selects the systematic (chromatic) scan, which is NOT
+// the reference's chain law (a host flag such as --scan systematic would set it).
+var ScanFlags uint32
+
+// RcclCalls reports how many ncclAllReduce calls gr_allreduce_counts has completed in this process.
+func RcclCalls() uint64 { return uint64(C.gr_rccl_calls()) }
+
 // NewHIPChains = NewGibbsSimple / NewGibbsCollapsed + NewChain for nChains chains.
 // variants > 1 builds `variants` collapsed groups (Collapse(-1) in each).
 func NewHIPChains(m *model.Model, nChains, variants, device int, seed int64, burnIn int64, collapse bool) (*HIPChains, error) {
@@ -144,7 +153,7 @@ func NewHIPChains(m *model.Model, nChains, variants, device int, seed int64, bur
 	o := C.gr_sampler_opts{
 		struct_size: C.uint32_t(unsafe.Sizeof(C.gr_sampler_opts{})),
 		n_chains: C.uint32_t(nChains), n_variants: C.uint32_t(variants),
-		device: C.int32_t(device), seed: C.uint64_t(seed),
+		device: C.int32_t(device), seed: C.uint64_t(seed), flags: C.uint32_t(ScanFlags),
 	}
 	h, err := create(gm, &o)
 	if err != nil {
