@@ -41,6 +41,10 @@ hipError_t launch_stop_time(const ScanArgs &a, uint32_t cw, uint32_t batch, uint
 hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half, const unsigned char *log, uint32_t log_pitch, uint32_t log_rows,
                               uint32_t log_vals, const uint32_t *limit, uint32_t *hist, uint32_t *status, uint32_t n_seg, uint32_t seg_chunks,
                               uint32_t *seg_cnt, hipStream_t s);
+// AdvanceChain under GR_FLAG_SCAN_PER_CHAIN: per-chain stopping times and ChainHistory halves (log: one value byte per chain and step)
+hipError_t launch_stop_time_pc(const ScanArgs &a, uint32_t n_chains, uint32_t n_free_max, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *out, hipStream_t s);
+hipError_t launch_ring_halves_pc(const ScanArgs &a, uint32_t n_chains, uint32_t n_free_max, uint32_t half, const unsigned char *log, uint32_t log_pitch,
+                                 const uint32_t *limit, uint32_t *hist, uint32_t *status, hipStream_t s);
 // value-parallel form of the direct path for large-Card pairwise models (sweep_pw4.hip): 64-chain blocks of 256 lanes
 hipError_t launch_sweep_pw4(const SweepParams &p, uint32_t blocks, uint32_t lds_bytes, hipStream_t s);
 // fast binary / memoised path (sweep_bin.hip)

@@ -256,12 +256,14 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     };
 
     // g.last[v] = val (gibbs-simple.go:267) and Marginal[val] += 1 (chain.go:230-236)
-    unsigned char *logrow = LOG && p.log ? p.log + (size_t)(chain >> 6) * p.log_rows * p.log_pitch + p.log_off : nullptr;
-    // LOG: the group's own stopping time inside the window (steps of this launch it still executes)
+    // (PC: the log holds one VALUE byte per chain and step, 64 bytes per group and step -- a wavefront's store is one line)
+    unsigned char *logrow = LOG && p.log ? (PC ? p.log + (size_t)(chain >> 6) * p.log_pitch + (size_t)p.log_off * 64u + lane
+                                               : p.log + (size_t)(chain >> 6) * p.log_rows * p.log_pitch + p.log_off) : nullptr;
+    // LOG: the group's (PC: the chain's) own stopping time inside the window (steps of this launch it still executes)
     uint32_t lim = 0xffffffffu;
     if constexpr (LOG)
         if (p.limit) {
-            const uint32_t t = p.limit[chain >> 6];
+            const uint32_t t = PC ? (active ? p.limit[chain] : 0u) : p.limit[chain >> 6];
             lim = t > p.win_off ? t - p.win_off : 0u;
         }
     auto commit = [&](const uint32_t v, cu32p pg, const uint32_t val, const uint32_t sidx) {
@@ -282,6 +284,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
                 }
             } else {
                 if (active) atomicAdd(&hist[ho + val], 1u);
+                if (LOG && PC && logrow && active) logrow[(size_t)sidx * 64u] = (unsigned char)val;
                 if (LOG && !PC && logrow) // one count per value (log_vals = max Card)
                     for (uint32_t c = 0; c < C; ++c) {
                         const uint32_t n = (uint32_t)__popcll(__ballot(active && val == c));
@@ -842,6 +845,85 @@ __global__ __launch_bounds__(64) void k_ring_halves(const ScanArgs a, uint32_t n
     if (n_seg == 1u && lane == 0 && half) status[g] = *rem; // (several segments: the verdict comes from the counts, above)
 }
 
+// ---- AdvanceChain under GR_FLAG_SCAN_PER_CHAIN: every chain has its own scan stream, hence its own stopping time and its own
+// rings (chain.go:184-215 and buffer/circular.go per chain, literally).  One thread per chain; the per-variable counters of a
+// block's chains sit in LDS as u16 (cw + 1 < 65 536 is checked by the host).
+__global__ void k_stop_time_pc(const ScanArgs a, uint32_t n_chains, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *out) {
+    extern __shared__ unsigned short sm_pc[];
+    const uint32_t chain = blockIdx.x * blockDim.x + threadIdx.x;
+    if (chain >= n_chains) return;
+    const uint32_t variant = chain / a.chains_per_variant;
+    const VariantDesc vd = a.variants[variant];
+    unsigned short *cnt = sm_pc + (size_t)threadIdx.x * vd.n_free; // by rank in the free list
+    for (uint32_t i = 0; i < vd.n_free; ++i) cnt[i] = 0;
+    const uint64_t gchain = (((uint64_t)a.chain_offset_hi << 32) | a.chain_offset_lo) + chain;
+    uint64_t s = ((uint64_t)a.step0_hi << 32) | a.step0_lo;
+    uint32_t remaining = vd.n_free, b = 0;
+    while (remaining && b < max_batches) {
+        const uint64_t e = s + batch;
+        for (uint64_t q = s >> 2; (q << 2) < e; ++q) {
+            const u32x4 w = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_SCAN_CHAIN + ((uint32_t)(gchain >> 32) << 4), a.seed_lo, a.seed_hi);
+            const uint32_t k[4] = {mul_hi_u32(w.x, vd.n_free), mul_hi_u32(w.y, vd.n_free), mul_hi_u32(w.z, vd.n_free), mul_hi_u32(w.w, vd.n_free)};
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const uint64_t st = (q << 2) + j;
+                if (st < s || st >= e) continue;
+                const uint32_t c = cnt[k[j]];
+                if (c <= cw) {
+                    cnt[k[j]] = (unsigned short)(c + 1u);
+                    if (c == cw) --remaining; // its (cw + 1)-th selection
+                }
+            }
+        }
+        s = e;
+        ++b;
+    }
+    out[chain] = remaining ? 0xffffffffu : b;
+}
+
+// log: one value byte per chain and step, [group][step][64 chains]; limit[chain] = steps of the window the chain executed.
+// Walking the chain's own window backwards: the newest `half` selections of a variable are its ring's second half, the `half`
+// before them the first; hist[g][h][H] adds up the 64 chains of group g.  status[g] counts rings that are not full.
+__global__ void __launch_bounds__(64) k_ring_halves_pc(const ScanArgs a, uint32_t n_chains, uint32_t half, const unsigned char *log, uint32_t log_pitch,
+                                                      const uint32_t *limit, uint32_t *hist, uint32_t *status) {
+    extern __shared__ unsigned short sm_pc[];
+    const uint32_t g = blockIdx.x, lane = threadIdx.x, chain = g * 64u + lane;
+    const uint32_t variant = (g * 64u) / a.chains_per_variant;
+    const VariantDesc vd = a.variants[variant];
+    uint32_t *h = reinterpret_cast<uint32_t *>(sm_pc);                  // [2][H] of the group
+    unsigned short *cnt = sm_pc + 4u * a.H + (size_t)lane * vd.n_free; // selections seen so far (walking backwards), by rank
+    for (uint32_t i = lane; i < 2u * a.H; i += 64u) h[i] = 0;
+    for (uint32_t i = 0; i < vd.n_free; ++i) cnt[i] = 0;
+    __syncthreads();
+    if (chain < n_chains && half) {
+        const uint64_t gchain = (((uint64_t)a.chain_offset_hi << 32) | a.chain_offset_lo) + chain;
+        const uint64_t s0 = ((uint64_t)a.step0_hi << 32) | a.step0_lo;
+        const uint32_t n = limit[chain];
+        const unsigned char *lg = log + (size_t)g * log_pitch + lane;
+        uint32_t remaining = vd.n_free;
+        for (uint64_t q = (s0 + n - 1u) >> 2; remaining && n && q + 1u > (s0 >> 2); --q) {
+            const u32x4 w = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_SCAN_CHAIN + ((uint32_t)(gchain >> 32) << 4), a.seed_lo, a.seed_hi);
+            const uint32_t k[4] = {mul_hi_u32(w.x, vd.n_free), mul_hi_u32(w.y, vd.n_free), mul_hi_u32(w.z, vd.n_free), mul_hi_u32(w.w, vd.n_free)};
+            for (int j = 3; j >= 0; --j) {
+                const uint64_t st = (q << 2) + (uint32_t)j;
+                if (st < s0 || st >= s0 + n) continue;
+                const uint32_t c = cnt[k[j]];
+                if (c >= 2u * half) continue;
+                cnt[k[j]] = (unsigned short)(c + 1u);
+                if (c + 1u == 2u * half) --remaining;
+                const uint32_t v = a.free_vars[vd.free_base + k[j]];
+                const uint32_t val = lg[(size_t)(st - s0) * 64u];
+                atomicAdd(&h[(c < half ? a.H : 0u) + a.hoff[v] + val], 1u); // the newest `half` -> second half
+            }
+            if (q == 0) break;
+        }
+        if (remaining) atomicAdd(&status[g], remaining);
+    }
+    __syncthreads();
+    for (uint32_t i = lane; i < 2u * a.H; i += 64u)
+        if (h[i]) atomicAdd(&hist[(size_t)g * 2u * a.H + i], h[i]);
+}
+
 #endif // GR_KSWEEP_PART == 0
 
 // ------------------------------------------------------------ host launchers
@@ -867,13 +949,16 @@ static hipError_t launch_sweep_t(const SweepParams &p, uint32_t blocks, uint32_t
 template <int MC>
 static hipError_t launch_sweep_mc(const SweepParams &p, bool cpt, bool tab_lds, bool pairwise, bool per_chain, bool state_global,
                                   uint32_t blocks, uint32_t threads, uint32_t lds_bytes, hipStream_t s) {
-    if (state_global) // state in global memory: tables from global memory too; no strict mode, no draw log
-        return (p.log || per_chain || tab_lds) ? hipErrorInvalidValue
+    if (state_global && p.log) // ... with the draw log: direct back-end only (like the LDS-state log instantiation)
+        return (per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, 0, true, true>(p, blocks, threads, lds_bytes, s);
+    if (state_global) // state in global memory: tables from global memory too; no strict mode
+        return (per_chain || tab_lds) ? hipErrorInvalidValue
                : cpt ? launch_sweep_t<MC, true, false, false, 0, false, true>(p, blocks, threads, lds_bytes, s)
                : pairwise ? launch_sweep_t<MC, false, false, true, 0, false, true>(p, blocks, threads, lds_bytes, s)
                           : launch_sweep_t<MC, false, false, false, 0, false, true>(p, blocks, threads, lds_bytes, s);
     if (p.sys_order) // systematic scan: direct back-end, tables from global memory, chain state in LDS
         return (p.log || per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, 2>(p, blocks, threads, lds_bytes, s);
+    if (p.log && per_chain) return (cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, 1, true>(p, blocks, threads, lds_bytes, s);
     if (p.log) return (per_chain || cpt || tab_lds) ? hipErrorInvalidValue : launch_sweep_t<MC, false, false, false, 0, true>(p, blocks, threads, lds_bytes, s);
     if (per_chain) return tab_lds ? launch_sweep_t<MC, false, true, false, 1>(p, blocks, threads, lds_bytes, s)
                                   : launch_sweep_t<MC, false, false, false, 1>(p, blocks, threads, lds_bytes, s);
@@ -974,6 +1059,32 @@ hipError_t launch_ring_halves(const ScanArgs &a, uint32_t n_steps, uint32_t half
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_ring_halves, dim3(a.n_groups, n_seg), dim3(64), lds, s, a, n_steps, half, log, log_pitch, log_rows, log_vals, limit, hist, status,
                        n_seg, seg_chunks, seg_cnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_stop_time_pc(const ScanArgs &a, uint32_t n_chains, uint32_t n_free_max, uint32_t cw, uint32_t batch, uint32_t max_batches, uint32_t *out, hipStream_t s) {
+    // threads per block: as many chains' u16 counters as fit 64 KiB of LDS
+    uint32_t t = 64;
+    while (t > 1 && (size_t)t * n_free_max * 2u > 64u * 1024u) t >>= 1;
+    const size_t lds = (size_t)t * n_free_max * 2u;
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_stop_time_pc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_stop_time_pc, dim3((n_chains + t - 1u) / t), dim3(t), lds, s, a, n_chains, cw, batch, max_batches, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_ring_halves_pc(const ScanArgs &a, uint32_t n_chains, uint32_t n_free_max, uint32_t half, const unsigned char *log, uint32_t log_pitch,
+                                 const uint32_t *limit, uint32_t *hist, uint32_t *status, hipStream_t s) {
+    hipError_t e0 = hipMemsetAsync(hist, 0, (size_t)a.n_groups * 2u * a.H * sizeof(uint32_t), s);
+    if (e0 != hipSuccess) return e0;
+    e0 = hipMemsetAsync(status, 0, (size_t)a.n_groups * sizeof(uint32_t), s);
+    if (e0 != hipSuccess) return e0;
+    const size_t lds = (size_t)2u * a.H * 4u + (size_t)64u * n_free_max * 2u;
+    if (lds > 160u * 1024u) return hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_ring_halves_pc), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_ring_halves_pc, dim3(a.n_groups), dim3(64), lds, s, a, n_chains, half, log, log_pitch, limit, hist, status);
     return hipGetLastError();
 }
 

@@ -188,6 +188,7 @@ struct gr_sampler {
     DevBuf<double> cs_tables, cs_out, cs_part;
     // ... gr_advance_chain ...
     DevBuf<uint32_t> ac_out, ac_limit, ac_hist, ac_status, ac_hoff, ac_segcnt;
+    bool cur_log_pc = false;          // the current window's log is per chain (strict mode): [group][step][64 value bytes]
     // ... gr_conditional
     DevBuf<int32_t> cd_state;
     DevBuf<double> cd_probs;
@@ -782,7 +783,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
             p.n_steps = n;
             p.log = cur_log; p.log_pitch = cur_log_pitch; p.log_rows = cur_log_rows; p.log_vals = cur_log_vals;
-            p.log_off = (uint32_t)(step - cur_log_step0) * cur_log_vals;
+            p.log_off = cur_log_pc ? (uint32_t)(step - cur_log_step0) : (uint32_t)(step - cur_log_step0) * cur_log_vals;
             p.limit = cur_limit; p.win_off = (uint32_t)(step - cur_log_step0);
             // strict mode runs the direct arithmetic (bit-identical to the memoised tables); with strict_fast the LDS table
             // area holds thresholds, so the views are read from global memory
@@ -819,7 +820,9 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         T = 256; blocks = (act + 255) / 256;
         generic(n_total);
     };
-    if (sysscan) {
+    if (cur_log_pc) {
+        generic_small(updates); // strict mode's logged windows: the generic kernel's per-chain scan with the per-chain log
+    } else if (sysscan) {
         // systematic scan: whole sweeps from a sweep boundary on the chromatic kernel, everything else (and every model that
         // kernel does not take) on the generic kernel's systematic mode -- same order, same draws, same thresholds
         auto sys_generic = [&](uint64_t n_total) {
@@ -1670,12 +1673,75 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
     return guarded([&] {
         if (!s) throw Error(GR_E_INVALID, "null sampler");
         if (cw < 2) throw Error(GR_E_INVALID, "ConvergenceWindow must be >= 2");
-        if (s->o.flags & GR_FLAG_SCAN_PER_CHAIN) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain is not available in strict per-chain scan mode");
         if (s->o.flags & GR_FLAG_SCAN_SYSTEMATIC) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain is the random scan's stopping rule (chain.go:184-215): use gr_advance_window with GR_FLAG_SCAN_SYSTEMATIC");
         s->use();
         if (s->dirty) s->rebuild();
-        if (s->stg) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain needs the chain state in LDS (model too large, or GR_FLAG_STATE_GLOBAL): use gr_advance_window");
         const uint32_t act = s->active_chains();
+        if (s->o.flags & GR_FLAG_SCAN_PER_CHAIN) {
+            // Strict mode: every chain has its own scan stream, so AdvanceChain is the reference's, chain by chain (chain.go:184-215):
+            // per-chain stopping times (k_stop_time_pc), a log of one value byte per chain and step written by the generic kernel's
+            // per-chain scan, per-chain rings (k_ring_halves_pc) added up per 64-chain group.
+            if (cw + 1u > 65535u) throw Error(GR_E_UNSUPPORTED, "ConvergenceWindow too large for the strict mode's 16-bit selection counters");
+            if (s->stg) throw Error(GR_E_UNSUPPORTED, "strict per-chain scan needs the chain state in LDS");
+            const uint32_t n_groups = (act + 63u) / 64u;
+            uint32_t nfree_max = 1;
+            for (const auto &im : s->image) nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)im.free_vars.size());
+            ScanArgs a{};
+            a.variants = s->d_variants.p; a.free_vars = s->d_free.p; a.n_groups = n_groups; a.chains_per_variant = s->cpv;
+            a.chain_offset_lo = (uint32_t)s->o.chain_offset; a.chain_offset_hi = (uint32_t)(s->o.chain_offset >> 32);
+            a.seed_lo = (uint32_t)s->o.seed; a.seed_hi = (uint32_t)(s->o.seed >> 32);
+            a.n_vars = (uint32_t)s->n_vars;
+            a.step0_lo = (uint32_t)s->step; a.step0_hi = (uint32_t)(s->step >> 32);
+            const uint32_t batch = 2u * (uint32_t)s->n_vars;
+            const uint32_t max_batches = (uint32_t)std::min<uint64_t>((1ull << 31) / batch, 1u << 20);
+            s->ac_out.alloc(act);
+            hip_check(launch_stop_time_pc(a, act, nfree_max, cw, batch, max_batches, s->ac_out.p, s->stream), "k_stop_time_pc");
+            std::vector<uint32_t> nb(act);
+            s->download(nb.data(), s->ac_out.p, (size_t)act * sizeof(uint32_t));
+            uint32_t worst = 0;
+            for (uint32_t b : nb) {
+                if (b == 0xffffffffu) throw Error(GR_E_UNSUPPORTED, "ConvergenceWindow too large: a chain would need more than 2^31 updates");
+                worst = std::max(worst, b);
+            }
+            const uint64_t L = (uint64_t)worst * batch;
+            const uint64_t pitch = L * 64u;
+            if ((uint64_t)n_groups * pitch > (16ull << 30) || pitch > 0xfffffff0ull)
+                throw Error(GR_E_UNSUPPORTED, "the strict mode's per-chain draw log of this window would exceed 16 GiB: use gr_advance_window");
+            s->d_log.alloc((size_t)n_groups * pitch);
+            std::vector<uint32_t> lim(act);
+            for (uint32_t c = 0; c < act; ++c) lim[c] = nb[c] * batch;
+            s->ac_limit.upload(lim, s->stream, s->stage);
+            s->cur_log = s->d_log.p; s->cur_log_pitch = (uint32_t)pitch; s->cur_log_rows = 1; s->cur_log_vals = 64; s->cur_log_step0 = s->step;
+            s->cur_limit = s->ac_limit.p; s->cur_log_pc = true;
+            struct Off { gr_sampler *s; ~Off() { s->cur_log = nullptr; s->cur_limit = nullptr; s->cur_log_rows = 1; s->cur_log_vals = 1; s->cur_log_pc = false; } } off{s};
+            s->run(L, true);
+            for (uint32_t c = 0; c < act; ++c) s->skipped_updates += L - (uint64_t)nb[c] * batch;
+            const size_t nH = (size_t)s->o.n_variants * s->H;
+            s->win_first.assign(nH, 0.0);
+            s->win_second.assign(nH, 0.0);
+            s->win_cw = (double)cw;
+            std::vector<uint32_t> hoff(s->n_vars + 1, 0);
+            for (int v = 0; v < s->n_vars; ++v) hoff[v + 1] = hoff[v] + (uint32_t)s->card[v];
+            s->ac_hoff.upload(hoff, s->stream, s->stage);
+            a.hoff = s->ac_hoff.p; a.H = (uint32_t)s->H;
+            s->ac_hist.alloc((size_t)n_groups * 2u * s->H);
+            s->ac_status.alloc(n_groups);
+            hip_check(launch_ring_halves_pc(a, act, nfree_max, cw / 2u, s->d_log.p, (uint32_t)pitch, s->ac_limit.p, s->ac_hist.p, s->ac_status.p, s->stream), "k_ring_halves_pc");
+            std::vector<uint32_t> hist((size_t)n_groups * 2u * s->H), status(n_groups);
+            s->download(hist.data(), s->ac_hist.p, hist.size() * sizeof(uint32_t));
+            s->download(status.data(), s->ac_status.p, n_groups * sizeof(uint32_t));
+            for (uint32_t st : status)
+                if (st) throw Error(GR_E_STATE, "a ChainHistory ring is not full after AdvanceChain (internal error)");
+            for (uint32_t g = 0; g < n_groups; ++g) {
+                const uint32_t variant = (g * 64u) / s->cpv;
+                for (int i = 0; i < s->H; ++i) {
+                    s->win_first[(size_t)variant * s->H + i] += hist[((size_t)g * 2u + 0u) * s->H + i];
+                    s->win_second[(size_t)variant * s->H + i] += hist[((size_t)g * 2u + 1u) * s->H + i];
+                }
+            }
+            if (out_updates) *out_updates = L;
+            return;
+        }
         if (act % 64u) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain needs a multiple of 64 chains");
         const uint32_t n_groups = act / 64u;
         ScanArgs a{};

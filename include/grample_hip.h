@@ -274,7 +274,11 @@ int gr_advance_window(gr_sampler *s, uint64_t updates_per_chain);
  * log every step's draws per group and the two halves of every ChainHistory ring (the variable's last
  * 2*(cw/2) selections, buffer/circular.go) are rebuilt exactly for gr_adapt / ChainConvergence; a window
  * whose log would exceed 16 GiB runs every group for the slowest group's length and keeps the halves of the
- * window in time instead. */
+ * window in time instead.
+ * With GR_FLAG_SCAN_PER_CHAIN (round 3) the rule is the reference's chain by chain: every chain has its own scan stream, its own
+ * stopping time and its own rings (one logged value byte per chain and step; k_stop_time_pc / k_ring_halves_pc); the halves
+ * returned are still summed per chain group.  Models whose chain state stays in global memory are served too.  Not available
+ * with GR_FLAG_SCAN_SYSTEMATIC (the rule belongs to the random scan). */
 int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_updates);
 /* the half-window histograms kept by the last gr_advance_window / gr_advance_chain:
  * first/second [n_variants * total_card] (inactive groups: zeros); *cw = the ConvergenceWindow they stand for */
