@@ -8,6 +8,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
 mkdir -p $O
+$R/scripts/ubench/issue_rate.bin > $O/issue_rate_ubench.txt 2>&1
 rm -f $O/seed_noise.txt
 python3 $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err || { tail -20 $O/bench.err; exit 1; }
 echo "bench done"; head -c 400 $O/bench.json; echo
@@ -29,6 +30,7 @@ echo "configs done"
 python3 $R/scripts/dev_time.py > $O/dev_time.txt 2>&1
 python3 $R/scripts/dev_od.py > $O/dev_od.txt 2>&1
 python3 $R/scripts/dev_wide.py > $O/dev_wide.txt 2>&1
+python3 $R/scripts/dev_systematic.py > $O/dev_systematic.txt 2>&1
 python3 $R/scripts/dev_all_models.py 32768 > $O/all_models_32768.txt 2>&1
 python3 $R/scripts/parity_configs.py > $O/parity_configs.jsonl 2> $O/parity_configs.err
 for spec in "ObjectDetection_13.uai 256 50 400" "Segmentation_11.uai 256 20 100" "Grids_13.uai 256 20 200"; do

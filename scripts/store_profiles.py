@@ -24,7 +24,7 @@ def kernel_rows(path, keep="gr::"):
 
 def main():
     for src, dst in (("bench.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("configs.jsonl", "configs.jsonl"),
-                     ("stats/run_kernel_stats.csv", "kernel_stats.csv"), ("dev_time.txt", "dev_time.txt"), ("dev_od.txt", "dev_od.txt"), ("dev_wide.txt", "dev_wide.txt"), ("issue_rate_ubench.txt", "issue_rate_ubench.txt"),
+                     ("stats/run_kernel_stats.csv", "kernel_stats.csv"), ("dev_time.txt", "dev_time.txt"), ("dev_od.txt", "dev_od.txt"), ("dev_wide.txt", "dev_wide.txt"), ("dev_systematic.txt", "dev_systematic.txt"), ("issue_rate_ubench.txt", "issue_rate_ubench.txt"),
                      ("all_models_32768.txt", "all_models_32768.txt"), ("parity_configs.jsonl", "parity_configs.jsonl"),
                      ("seed_noise.txt", "seed_noise.txt"), ("advance_chain.txt", "advance_chain.txt")):
         if os.path.exists(os.path.join(G, src)):
