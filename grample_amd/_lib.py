@@ -89,6 +89,7 @@ SIGNATURES = {
     "gr_advance_window": (C.c_int, [vp, u64]),
     "gr_advance_chain": (C.c_int, [vp, u32, pu64]),
     "gr_window_halves": (C.c_int, [vp, pd, pd, pd]),
+    "gr_set_window_halves": (C.c_int, [vp, pd, pd, dbl]),
     "gr_chain_convergence": (C.c_int, [i32, i32, pi32, pi32, pi32, pd, pd, pd, dbl, i32, pd]),
     "gr_adapt_select": (C.c_int, [vp, pi32, pd, u32, pi32, pu32]),
     "gr_adapt": (C.c_int, [vp, u32, pi32, pu32, pd]),

@@ -313,8 +313,14 @@ class HIPChains:
         _chk(self.L.gr_get_position(self.ptr, C.byref(pos), _p(cg, C.c_uint64), _p(ep, C.c_uint32)))
         st = np.zeros((self.n_vars, self.n_chains), dtype=np.uint8)
         _chk(self.L.gr_state_download(self.ptr, _p(st, C.c_uint8)))
-        return {"states": st, "counts": self.counts(), "counted_per_group": cg, "epoch_per_group": ep,
-                "position": {k: getattr(pos, k) for k, _ in Position._fields_ if k != "struct_size"}}
+        ck = {"states": st, "counts": self.counts(), "counted_per_group": cg, "epoch_per_group": ep,
+              "position": {k: getattr(pos, k) for k, _ in Position._fields_ if k != "struct_size"}}
+        try:  # the ChainHistory halves of the last AdvanceChain / AdvanceWindow, if there was one
+            a, b, cw = self.window_halves()
+            ck["window"] = (a, b, cw)
+        except GrError:
+            pass
+        return ck
 
     def restore(self, ck):
         st = np.ascontiguousarray(ck["states"], dtype=np.uint8)
@@ -324,6 +330,10 @@ class HIPChains:
         cg = np.ascontiguousarray(ck["counted_per_group"], dtype=np.uint64)
         ep = np.ascontiguousarray(ck["epoch_per_group"], dtype=np.uint32)
         _chk(self.L.gr_set_position(self.ptr, C.byref(pos), _p(cg, C.c_uint64), _p(ep, C.c_uint32)))
+        if "window" in ck:
+            a, b, cw = ck["window"]
+            a, b = _f64(a), _f64(b)
+            _chk(self.L.gr_set_window_halves(self.ptr, _p(a, C.c_double), _p(b, C.c_double), float(cw)))
 
     def merge_local(self):
         s, cm = np.zeros(self.H), np.zeros(self.H)

@@ -77,7 +77,20 @@ struct PinnedArena {
         used += bytes;
         return out;
     }
-    void reset() { cur = 0; used = 0; } // only once nothing in flight reads or writes the arena
+    // only once nothing in flight reads or writes the arena.  Blocks are kept for the next call (allocating pinned memory is
+    // slow) up to a watermark: a one-off bulk transfer -- gr_state_download of a million chains is 400 MB -- must not stay
+    // page-locked for the sampler's lifetime.
+    void reset() {
+        cur = 0; used = 0;
+        size_t total = 0;
+        for (const auto &b : blocks) total += b.cap;
+        while (total > kKeep && !blocks.empty()) {
+            total -= blocks.back().cap;
+            (void)hipHostFree(blocks.back().p);
+            blocks.pop_back();
+        }
+    }
+    static constexpr size_t kKeep = size_t(64) << 20;
 };
 
 template <class T>
@@ -226,8 +239,9 @@ struct gr_sampler {
         if (!bytes) { sync(); return; }
         void *tmp = stage.take(bytes);
         hip_check(hipMemcpyAsync(tmp, dsrc, bytes, hipMemcpyDeviceToHost, stream), "D2H");
-        sync();
-        memcpy(dst, tmp, bytes); // (reset() only rewinds the arena: the bytes are still there)
+        hip_check(hipStreamSynchronize(stream), "hipStreamSynchronize");
+        memcpy(dst, tmp, bytes); // (before the arena is reset: a reset may give blocks above the watermark back)
+        stage.reset();
     }
     PinnedArena stage;
 
@@ -1473,8 +1487,10 @@ GR_VISIBLE int gr_set_position(gr_sampler *s, const gr_position *pos, const uint
         s->step = pos->step;
         s->counted = pos->counted;
         s->skipped_updates = pos->skipped_updates;
+        if (!counted_per_group && s->o.n_variants > 1)
+            throw Error(GR_E_INVALID, "gr_set_position: counted_per_group is required for a sampler with several chain groups");
         if (counted_per_group) s->counted_g.assign(counted_per_group, counted_per_group + s->o.n_variants);
-        else if (s->o.n_variants == 1) s->counted_g.assign(1, pos->counted);
+        else s->counted_g.assign(1, pos->counted);
         if (epoch_per_group) s->epoch.assign(epoch_per_group, epoch_per_group + s->o.n_variants);
         s->started = s->started || pos->step > 0;
     });
@@ -1486,8 +1502,9 @@ GR_VISIBLE int gr_state_download(gr_sampler *s, uint8_t *states) {
         const size_t bytes = (size_t)s->o.n_chains * s->n_vars;
         void *tmp = s->stage.take(bytes);
         hip_check(hipMemcpy2DAsync(tmp, s->o.n_chains, s->d_state.p, s->pitch, s->o.n_chains, s->n_vars, hipMemcpyDeviceToHost, s->stream), "D2H state");
-        s->sync();
-        memcpy(states, tmp, bytes);
+        hip_check(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
+        memcpy(states, tmp, bytes); // (before the arena is reset: this one may be above its watermark)
+        s->stage.reset();
     });
 }
 GR_VISIBLE int gr_state_upload(gr_sampler *s, const uint8_t *states) {
@@ -1778,6 +1795,7 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         std::vector<uint64_t> c0(nH), c1(nH), c2(nH);
         DevBuf<uint32_t> &d_limit = s->ac_limit;
         if (logging) {
+            if (d_log.cap > (size_t(256) << 20) && d_log.cap > 4u * ((size_t)n_groups * rows * pitch)) d_log.reset(); // a much shorter window: give the big log back
             d_log.alloc((size_t)n_groups * rows * pitch); // (keeps a large enough allocation of an earlier window)
             hip_check(hipMemsetAsync(d_log.p, 0, (size_t)n_groups * rows * pitch, s->stream), "hipMemset");
             s->cur_log = d_log.p; s->cur_log_pitch = (uint32_t)pitch; s->cur_log_rows = rows; s->cur_log_vals = log_vals; s->cur_log_step0 = s->step;
@@ -1851,6 +1869,17 @@ GR_VISIBLE int gr_window_halves(gr_sampler *s, double *first, double *second, do
         std::copy(s->win_first.begin(), s->win_first.end(), first);
         std::copy(s->win_second.begin(), s->win_second.end(), second);
         if (cw) *cw = s->win_cw;
+    });
+}
+
+GR_VISIBLE int gr_set_window_halves(gr_sampler *s, const double *first, const double *second, double cw) {
+    return guarded([&] {
+        if (!s || !first || !second) throw Error(GR_E_INVALID, "null argument");
+        if (!(cw >= 2.0)) throw Error(GR_E_INVALID, "ConvergenceWindow must be >= 2");
+        const size_t n = (size_t)s->o.n_variants * s->H;
+        s->win_first.assign(first, first + n);
+        s->win_second.assign(second, second + n);
+        s->win_cw = cw;
     });
 }
 
@@ -2003,8 +2032,9 @@ GR_VISIBLE int gr_state(gr_sampler *s, uint32_t chain, int32_t *out) {
         std::vector<unsigned char> col(s->n_vars);
         void *tmp = s->stage.take(s->n_vars);
         hip_check(hipMemcpy2DAsync(tmp, 1, s->d_state.p + chain, s->pitch, 1, s->n_vars, hipMemcpyDeviceToHost, s->stream), "D2H state");
-        s->sync();
+        hip_check(hipStreamSynchronize(s->stream), "hipStreamSynchronize");
         memcpy(col.data(), tmp, s->n_vars);
+        s->stage.reset();
         for (int v = 0; v < s->n_vars; ++v) out[v] = col[v];
     });
 }

@@ -176,8 +176,9 @@ int gr_counts_upload(gr_sampler *s, const uint64_t *counts); /* overwrite the ra
 
 /* ------------------------------------------------------ checkpoint / resume
  * The reference has none (its trace is write-only); with a counter-based RNG a
- * sampler's whole condition is: the chain states, the raw counts and this
- * position.  To resume: build the sampler exactly as before (same model, opts,
+ * sampler's whole condition is: the chain states, the raw counts, this position
+ * and -- for an adaptive sampler between gr_advance_chain and gr_adapt -- the
+ * ChainHistory halves of the last window (gr_window_halves / gr_set_window_halves).  To resume: build the sampler exactly as before (same model, opts,
  * and the same gr_collapse / gr_activate_group calls with explicit variables),
  * then gr_state_upload + gr_counts_upload + gr_set_position; every later
  * gr_burnin / gr_advance continues the Philox streams where the checkpointed
@@ -191,7 +192,8 @@ typedef struct gr_position {
     uint64_t skipped_updates; /* updates not made inside gr_advance_chain windows by groups that stopped early */
 } gr_position;
 /* counted_per_group [n_variants] (counted updates per chain of each group) and
- * epoch_per_group [n_variants] (start-state re-draw counter, gibbs-simple.go:132-142) may be NULL */
+ * epoch_per_group [n_variants] (start-state re-draw counter, gibbs-simple.go:132-142) may be NULL in gr_get_position;
+ * gr_set_position requires counted_per_group for a sampler with more than one chain group */
 int gr_get_position(gr_sampler *s, gr_position *pos, uint64_t *counted_per_group, uint32_t *epoch_per_group);
 /* pos->n_active must equal the sampler's: groups are re-created by replaying the collapses, not by this call */
 int gr_set_position(gr_sampler *s, const gr_position *pos, const uint64_t *counted_per_group, const uint32_t *epoch_per_group);
@@ -283,6 +285,8 @@ int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_updates);
 /* the half-window histograms kept by the last gr_advance_window / gr_advance_chain:
  * first/second [n_variants * total_card] (inactive groups: zeros); *cw = the ConvergenceWindow they stand for */
 int gr_window_halves(gr_sampler *s, double *first, double *second, double *cw);
+/* restore them (checkpoint / resume of an adaptive sampler: the next gr_adapt ranks with these) */
+int gr_set_window_halves(gr_sampler *s, const double *first, const double *second, double cw);
 /* ChainConvergence (chain.go:32-92) as a pure function: first/second [n_groups*total_card] half-window
  * histograms (any non-negative numbers; 1e-8 is added like ChainDist does), merged [total_card],
  * merged_collapsed [n_vars] (may be NULL), cw = ConvergenceWindow, measure 0 Hellinger / 1 JS /

@@ -336,3 +336,39 @@ def test_experiment_trace_file(res_dir, tmp_path):
     # experiment mode without a trace file is refused like root.go:315-317
     bad = subprocess.run([exe, "-m", os.path.join(res_dir, name), "-o", "--experiment"], capture_output=True, text=True, timeout=60)
     assert bad.returncode != 0 and "requires a trace file" in bad.stderr
+
+
+def test_checkpoint_resume_of_an_adaptive_sampler_across_adapt(res_dir):
+    """the ChainHistory halves of the last window are part of an adaptive sampler's condition (gr_adapt ranks with
+    them).  A sampler rebuilt from a checkpoint taken between AdvanceChain and Adapt picks the same variables and then samples
+    the same counts as the uninterrupted run; gr_set_position refuses a multi-group restore without the per-group totals."""
+    import ctypes as Cc
+    from grample_amd._lib import Position
+    name = "Segmentation_11.uai"
+    gm = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+
+    def fresh():
+        s = g.HIPChains.NewGibbsCollapsed(gm, 8 * 64, 8, seed=31)
+        s.set_active_groups(2)
+        return s
+    a = fresh()
+    a.BurnIn(500)
+    a.AdvanceChain(10)
+    ck = a.checkpoint()
+    assert "window" in ck
+    picks_a, conv_a = a.Adapt(3)
+    a.AdvanceChain(10)
+    b = fresh()
+    with pytest.raises(g.GrError):  # per-group totals are required for several chain groups
+        pos = Position(Cc.sizeof(Position), *[ck["position"][k] for k, _ in Position._fields_ if k != "struct_size"])
+        assert b.L.gr_set_position(b.ptr, Cc.byref(pos), None, None) != 0
+        raise g.GrError(-1, b.L.gr_last_error().decode())
+    b.restore(ck)
+    assert b.TotalSampleCount() == ck["counts"].sum()
+    picks_b, conv_b = b.Adapt(3)
+    assert picks_a == picks_b and np.allclose(conv_a, conv_b, rtol=0, atol=0, equal_nan=True)
+    b.AdvanceChain(10)
+    assert np.array_equal(a.counts(), b.counts()) and a.TotalSampleCount() == b.TotalSampleCount()
+    wa, wb = a.window_halves(), b.window_halves()
+    assert np.array_equal(wa[0], wb[0]) and np.array_equal(wa[1], wb[1])
+    assert np.array_equal(a.checkpoint()["states"], b.checkpoint()["states"])
