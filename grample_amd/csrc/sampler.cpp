@@ -949,10 +949,10 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             if (o.fast_form == 8) lpc = 8;
             else if (o.fast_form == 9) lpc = 16;
             else if (o.fast_form == 0 && groups * 16u <= 4096u && par_rec_off * 4u <= kLdsBudget) lpc = 16;
-            // (records of more than 8 slots make the wide kernel's two record sets cost more than 128 registers: a CU then holds ONE
-            // 512-lane block -- fine while there is at most one per CU to run, a loss beyond: Segmentation_11 at 32 768 chains 4.1e11
-            // with 4 lanes, 3.1e11 with 8)
-            else if (o.fast_form == 0 && groups * 8u <= (fast_slots <= 8 ? 4096u : 2048u)) lpc = 8;
+            // (records of more than 4 slots make the wide kernel's two record sets cost more than 128 registers: a CU then holds ONE
+            // 512-lane block -- fine while there is at most one per CU to run, a loss beyond: Segmentation_11 (8 slots) at 32 768
+            // chains 4.2e11 with 4 lanes, 3.2e11 with 8)
+            else if (o.fast_form == 0 && groups * 8u <= (fast_slots <= 4 ? 4096u : 2048u)) lpc = 8;
         }
         if (par) lpc_last = lpc;
         const uint64_t gran = strict_fast ? 4 : par ? 4u * lpc : 4; // steps per inner iteration of the fast kernels
