@@ -695,3 +695,22 @@ def test_group_scan_equals_per_chain_scan_in_law(res_dir, name, sweeps):
     se = np.sqrt(ps[0].var(axis=0, ddof=1) / G + ps[1].var(axis=0, ddof=1) / G)
     z = (ps[0].mean(axis=0) - ps[1].mean(axis=0)) / np.maximum(se, 2e-4)
     assert np.max(np.abs(z)) <= 5.5 and np.mean(z ** 2) <= 2.0, (np.max(np.abs(z)), np.mean(z ** 2))
+
+
+def test_kernel_selection_table():
+    """The kernel / layout choices of gr_sampler (sampler.cpp: configure, configure_impl, run -- thresholds measured on the 19
+    fixture models) as one observable table: every fixture model, with and without evidence, 512 .. 262 144 chains, random and
+    systematic scan -> path, lanes per chain, tables in LDS.  tests/golden/path_table.json is the recorded table
+    (scripts/path_table.py --json); a change of a threshold shows up here and must be re-recorded deliberately."""
+    import json
+    from scripts import path_table
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = json.load(open(os.path.join(root, "tests", "golden", "path_table.json")))
+    got = path_table.rows()
+    key = lambda x: (x["model"], x["evidence"], x.get("chains"), x.get("scan"))  # noqa: E731
+    gw, gg = {key(x): x for x in want}, {key(x): x for x in got}
+    assert gw.keys() == gg.keys()
+    diff = [(k, {f: (gw[k].get(f), gg[k].get(f)) for f in ("path", "lanes_per_chain", "tables_in_lds", "error") if gw[k].get(f) != gg[k].get(f)}) for k in gw]
+    diff = [d for d in diff if d[1]]
+    assert not diff, diff[:10]
+    assert len({x["path"] for x in got if "path" in x}) >= 6  # the fixtures exercise direct, memoised, 4-lane, value-parallel, step-parallel, chromatic
