@@ -943,16 +943,15 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         uint32_t lpc = 4;
         if (par && wide_ok && !no_wide && !cur_log && !cur_limit) {
             const uint32_t groups = act / 64u;
-            // measured (scripts/dev_wide.py -> profiles/r03_dev_wide.txt): 16 lanes pay while 16 x groups <= 4 096 wavefronts AND the
-            // block's LDS footprint lets a CU hold four of them (one-wavefront blocks spread over the CUs); 8 lanes while 8 x groups
-            // <= 4 096; beyond that the 4-lane form has the chip full and the wider forms' extra passes only cost
+            // measured (scripts/dev_wide.py -> profiles/r03_dev_wide.txt): 16 lanes pay while 16 x groups <= 4 096 wavefronts AND either
+            // the block's LDS footprint lets a CU hold four of them or the whole launch fits the chip as one-wavefront blocks (each
+            // with its own copy of the tables: the first rounds of an adaptive run); 8 lanes while 8 x groups <= 4 096; beyond that the
+            // 4-lane form has the chip full and the wider forms' extra passes only cost
+            const uint32_t fit = kLdsBudget / std::max(par_rec_off, 1u);
             if (o.fast_form == 8) lpc = 8;
             else if (o.fast_form == 9) lpc = 16;
-            else if (o.fast_form == 0 && groups * 16u <= 4096u && par_rec_off * 4u <= kLdsBudget) lpc = 16;
-            // (records of more than 4 slots make the wide kernel's two record sets cost more than 128 registers: a CU then holds ONE
-            // 512-lane block -- fine while there is at most one per CU to run, a loss beyond: Segmentation_11 (8 slots) at 32 768
-            // chains 4.2e11 with 4 lanes, 3.2e11 with 8)
-            else if (o.fast_form == 0 && groups * 8u <= (fast_slots <= 4 ? 4096u : 2048u)) lpc = 8;
+            else if (o.fast_form == 0 && groups * 16u <= 4096u && (fit >= 4u || groups * 16u <= 256u * fit)) lpc = 16;
+            else if (o.fast_form == 0 && groups * 8u <= 4096u) lpc = 8;
         }
         if (par) lpc_last = lpc;
         const uint64_t gran = strict_fast ? 4 : par ? 4u * lpc : 4; // steps per inner iteration of the fast kernels

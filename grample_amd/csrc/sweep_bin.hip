@@ -992,7 +992,7 @@ __global__ void __launch_bounds__(256) k_scan_plan_wide(const FastParams p) {
 }
 
 template <int LPC, int SLOTS, int MODE, int TABG> // MODE 0: burn-in, 1: count
-__global__ void __launch_bounds__(64 * LPC) k_sweep_wide(const FastParams p) {
+__global__ void __launch_bounds__(64 * LPC, 4) k_sweep_wide(const FastParams p) { // (4 wavefronts per SIMD: <= 128 registers)
     constexpr bool COUNT = MODE != 0, PACKED = true;
     constexpr uint32_t W = 64u / LPC, E = LPC / 4u;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -1042,21 +1042,31 @@ __global__ void __launch_bounds__(64 * LPC) k_sweep_wide(const FastParams p) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) pwa[k] = __builtin_amdgcn_raw_buffer_load_b32(plan_rsrc, j4, min(round0 + (uint32_t)k, n_rounds - 1u) * (4u * LPC), 0);
     };
+    // Records: SLOTS <= 4 -- the four records of the NEXT iteration in flight while the current one runs (two register sets of
+    // four, like k_sweep_par4); SLOTS > 4 -- ONE record ahead (two sets of one, the next round's fetched while the current round
+    // runs): two sets of four 12..20-word records are 96..160 registers, and above 128 a CU holds one 512-lane block where its
+    // LDS would take two (Segmentation_11, Promedus, collapsed groups).
+    constexpr bool ROUND_AHEAD = SLOTS > 4;
+    constexpr int NSET = ROUND_AHEAD ? 1 : 4;
     uint32_t pwA[4] = {0, 0, 0, 0}, pwB[4] = {0, 0, 0, 0};
-    RecL<SLOTS, PACKED> rA[4], rB[4];
-    auto prefetch = [&](RecL<SLOTS, PACKED> (&rx)[4], uint32_t (&pwx)[4]) { // the iteration whose plan words are in pwa
+    RecL<SLOTS, PACKED> rA[NSET], rB[NSET];
+    auto fetch = [&](RecL<SLOTS, PACKED> &r, const uint32_t pw) {
+        const unsigned char *ga = recs_g + (pw & kWideOffMask);
+        r.h = *reinterpret_cast<const uint4 *>(ga);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(r.s) / sizeof(uint4)); ++i) r.s[i] = *reinterpret_cast<const uint4 *>(ga + 16 + 16 * i);
+    };
+    auto prefetch = [&](RecL<SLOTS, PACKED> (&rx)[NSET], uint32_t (&pwx)[4]) { // the iteration whose plan words are in pwa
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             pwx[k] = pwa[k];
-            const unsigned char *ga = recs_g + (pwx[k] & kWideOffMask);
-            rx[k].h = *reinterpret_cast<const uint4 *>(ga);
-#pragma unroll
-            for (int i = 0; i < (int)(sizeof(rx[0].s) / sizeof(uint4)); ++i) rx[k].s[i] = *reinterpret_cast<const uint4 *>(ga + 16 + 16 * i);
+            if constexpr (!ROUND_AHEAD) fetch(rx[k], pwx[k]);
         }
     };
     prefetch_plan(0); prefetch(rA, pwA); prefetch_plan(4);
+    if constexpr (ROUND_AHEAD) fetch(rA[0], pwA[0]); // round 0's record; from here on set A serves the even rounds, set B the odd ones
 
-    auto iteration = [&](const uint32_t it, RecL<SLOTS, PACKED> (&rc)[4], uint32_t (&pwc)[4], RecL<SLOTS, PACKED> (&rx)[4], uint32_t (&pwx)[4]) {
+    auto iteration = [&](const uint32_t it, RecL<SLOTS, PACKED> (&rc)[NSET], uint32_t (&pwc)[4], RecL<SLOTS, PACKED> (&rx)[NSET], uint32_t (&pwx)[4]) {
         // draws: my Philox call is quad it * LPC + slot; two lane-swap pairs leave U[k] = my word of round k (see the header)
         const uint64_t q = q0 + (uint64_t)it * LPC + slot;
         const u32x4 Wd = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
@@ -1071,7 +1081,9 @@ __global__ void __launch_bounds__(64 * LPC) k_sweep_wide(const FastParams p) {
         prefetch(rx, pwx); prefetch_plan(it * 4u + 8u);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const RecL<SLOTS, PACKED> r = rc[k];
+            // ROUND_AHEAD: rc[0] = set A (even rounds), rx[0] = set B (odd rounds): fetch the next round's record into the other set
+            if constexpr (ROUND_AHEAD) fetch((k & 1) ? rc[0] : rx[0], k < 3 ? pwc[k + 1] : pwx[0]);
+            const RecL<SLOTS, PACKED> r = ROUND_AHEAD ? ((k & 1) ? rx[0] : rc[0]) : rc[ROUND_AHEAD ? 0 : k];
             const uint32_t pw = pwc[k];
             const bool val = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
             unsigned long long drawn = __ballot(val);
@@ -1097,9 +1109,20 @@ __global__ void __launch_bounds__(64 * LPC) k_sweep_wide(const FastParams p) {
             }
         }
     };
-    for (uint32_t it = 0; it < n_it; it += 2) {
-        iteration(it, rA, pwA, rB, pwB);
-        if (it + 1u < n_it) iteration(it + 1u, rB, pwB, rA, pwA);
+    if constexpr (ROUND_AHEAD) {
+        // (the record sets do not swap roles between iterations: 4 rounds per iteration, set A always serves rounds 0 and 2)
+        for (uint32_t it = 0; it < n_it; it += 2) {
+            iteration(it, rA, pwA, rB, pwB);
+            if (it + 1u < n_it) {
+                // second iteration of the pair: plan words live in pwB now, the record sets keep their parity
+                iteration(it + 1u, rA, pwB, rB, pwA);
+            }
+        }
+    } else {
+        for (uint32_t it = 0; it < n_it; it += 2) {
+            iteration(it, rA, pwA, rB, pwB);
+            if (it + 1u < n_it) iteration(it + 1u, rB, pwB, rA, pwA);
+        }
     }
 
     for (uint32_t v = slot; v < p.n_vars; v += LPC) p.state[(size_t)v * p.pitch + chain] = lds[v * p.par_stride + cb];

@@ -322,8 +322,12 @@ def test_model_larger_than_lds_runs_from_global_state():
     s.Advance(150); em.run(150, True)
     assert np.array_equal(s.counts()[0], em.counts)
     assert np.array_equal(s.checkpoint()["states"].astype(np.int64), em.state)
-    with pytest.raises(g.GrError):
-        s.AdvanceChain(4)  # the draw log needs the LDS-state kernel
+    # AdvanceChain on a global-state model (round 3; the small cases are replayed by the emulator in test_gpu_collapse.py): whole
+    # batches of 2 N, and every variable's ring halves hold cw / 2 selections of each of the 128 chains
+    Lw = s.AdvanceChain(4)
+    assert Lw % (2 * n) == 0 and Lw >= 5 * n
+    a, b, cw = s.window_halves()
+    assert cw == 4 and np.all(a[0].reshape(n, 2).sum(axis=1) == 128 * 2) and np.all(b[0].reshape(n, 2).sum(axis=1) == 128 * 2)
 
 
 def _pairwise_big_card_model(rng, n=24):
