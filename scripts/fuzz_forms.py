@@ -71,7 +71,8 @@ def main():
         ref = run(m, chains, seed, off)
         forms = {"chain_per_lane": dict(fast_form=1), "direct": dict(flags=g.GR_FLAG_DIRECT), "sequential": dict(flags=g.GR_FLAG_SEQUENTIAL),
                  "state_global": dict(flags=g.GR_FLAG_STATE_GLOBAL), "state_global_direct": dict(flags=g.GR_FLAG_STATE_GLOBAL | g.GR_FLAG_DIRECT),
-                 "form2": dict(fast_form=2), "form6": dict(fast_form=6), "form7_split_pool": dict(fast_form=7)}
+                 "form2": dict(fast_form=2), "form3_no_wide": dict(fast_form=3), "form6": dict(fast_form=6), "form7_split_pool": dict(fast_form=7),
+                 "form8_wide8": dict(fast_form=8), "form9_wide16": dict(fast_form=9)}
         paths = [ref[0]]
         for name, kw in forms.items():
             try:
@@ -89,6 +90,14 @@ def main():
             b = run(m, chains, seed, off, flags=g.GR_FLAG_SCAN_PER_CHAIN | g.GR_FLAG_DIRECT)
             assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (i, kind, "strict")
             paths += [a[0], b[0]]
+        except g.GrError:
+            pass
+        # systematic scan: chromatic kernel (when the model qualifies) vs the generic kernel's systematic mode
+        try:
+            a = run(m, chains, seed, off, flags=g.GR_FLAG_SCAN_SYSTEMATIC)
+            b = run(m, chains, seed, off, flags=g.GR_FLAG_SCAN_SYSTEMATIC | g.GR_FLAG_DIRECT)
+            assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (i, kind, "systematic")
+            paths += [a[0] + 100, b[0] + 100]
         except g.GrError:
             pass
         for p in paths:

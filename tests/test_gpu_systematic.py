@@ -143,3 +143,27 @@ def test_systematic_flag_rules(res_dir):
     u = g.HIPChains(m, 256, flags=SYS, seed=1)
     u.restore(ck); u.Advance(333)
     assert np.array_equal(t.counts(), u.counts())
+
+
+def test_systematic_scan_after_collapse_vs_emulator(res_dir):
+    """GibbsCollapsed + systematic scan: the collapsed variable leaves the order, the COLLAPSE factor makes its former neighbours
+    mutually adjacent (they may no longer share a colour); replayed bit for bit, chromatic and generic kernels."""
+    from tests.test_gpu_parity import _thresholds_from_device
+    pm = exact_chain.tiny_models()["grid3x3"]
+    for flags, path in ((SYS, 9), (SYS | g.GR_FLAG_DIRECT, 0)):
+        s = g.HIPChains.NewGibbsCollapsed(_gm(pm), 128, 1, seed=77, flags=flags)
+        v, marg = s.Collapse(0, 4)  # the centre of the 3 x 3 grid: neighbours 1, 3, 5, 7
+        assert v == 4 and s.info()["path"] == path
+        scopes = [sc for sc in pm.scopes if 4 not in sc] + [[1, 3, 5, 7]]
+        order, color = systematic_order(pm.card, pm.fixed, scopes, collapsed={4})
+        assert 4 not in order and len({color[u] for u in (1, 3, 5, 7)}) == 4
+        em = Emulator(pm.card, pm.fixed, [u for u in range(9) if u != 4], _thresholds_from_device(s, pm.card), 128, 77, systematic=order)
+        from tests.emulator import init_state
+        em.state = init_state(pm.card, pm.fixed, 128, 77, 0, epoch=1)  # Collapse re-draws the start state (gibbs-simple.go:132-142)
+        s.BurnIn(11); em.run(11, False)
+        s.Advance(203); em.run(203, True)
+        assert np.array_equal(s.counts()[0], em.counts)
+        assert s.counts()[0][8:10].sum() == 0  # the collapsed variable is never sampled
+        for c in (0, 127):
+            got, want = s.LastSample(c), em.state[:, c]
+            assert np.array_equal(np.delete(got, 4), np.delete(want, 4))
