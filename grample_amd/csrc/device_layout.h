@@ -123,6 +123,7 @@ struct FastParams {
     const uint32_t *recs_chroma;
     const uint32_t *sys_pos;     // position in the sweep order of every entry of the free list (the draw stream's key)
     uint32_t chroma_row, chroma_tab_off, chroma_wpb, chroma_hist_off;
+    uint32_t chroma_rec_off;     // 0 = the lanes' records live in registers (k_sweep_chroma); else their LDS offset (k_sweep_chroma_l)
     uint32_t par_tab_words;      // k_sweep_par4 with tab_global: the first par_tab_words words of every group's pool are staged in LDS all
                                  // the same (split pool; record word 2 carries bit 31 for a table that stayed in global memory)
 };

@@ -165,7 +165,7 @@ struct gr_sampler {
     uint32_t par_stride = 80;         // ... bytes between the LDS state rows of consecutive variables
     bool sysscan = false;             // GR_FLAG_SCAN_SYSTEMATIC
     bool chroma = false;              // ... on k_sweep_chroma (binary memoised, few lane slots); else the generic kernel's systematic mode
-    uint32_t chroma_row = 0, chroma_tab_off = 0, chroma_hist_off = 0, chroma_lds = 0, chroma_nslot = 0, sys_n_free = 0, chroma_wpb = 4;
+    uint32_t chroma_row = 0, chroma_tab_off = 0, chroma_hist_off = 0, chroma_rec_off = 0, chroma_lds = 0, chroma_nslot = 0, sys_n_free = 0, chroma_wpb = 4;
     DevBuf<uint32_t> d_sys_order, d_sys_pos, d_chroma_slots, d_recs_chroma;
     bool no_wide = false;             // fast_form 3: every automatic choice, but never the wide form (measurements)
     bool wide_ok = false;             // ... the 8 / 16 lanes-per-chain form (k_sweep_wide) may take its place when wavefronts are what a launch lacks
@@ -271,7 +271,7 @@ void gr_sampler::configure() {
     if (sysscan) {
         if (stg) throw Error(GR_E_UNSUPPORTED, "GR_FLAG_SCAN_SYSTEMATIC needs the chain state in LDS (model too large, or GR_FLAG_STATE_GLOBAL)");
         sys_n_free = (uint32_t)image[0].free_vars.size();
-        bool ok = fast && cpt && fast_slots <= 8 && n_vars < 65536 && !(o.flags & (GR_FLAG_DIRECT | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE)) &&
+        bool ok = fast && cpt && fast_slots <= 12 && n_vars < 65536 && !(o.flags & (GR_FLAG_DIRECT | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE)) &&
                   (o.n_chains % 16u) == 0 && o.fast_form != 1;
         uint32_t nslot = 0, cpt_max = 0;
         for (const auto &im : image) {
@@ -295,8 +295,14 @@ void gr_sampler::configure() {
         if (chroma_wpb != 1 && chroma_wpb != 2 && chroma_wpb != 4 && chroma_wpb != 8 && chroma_wpb != 16) chroma_wpb = 16;
         chroma_tab_off = chroma_wpb * chroma_row;
         chroma_hist_off = chroma_tab_off + cpt_max * 4u;
+        chroma_rec_off = 0;
         chroma_lds = chroma_hist_off + 8u * sys_n_free;
-        chroma = ok && nslot <= 4 && chroma_lds <= kLdsBudget;
+        if (nslot > 4 || fast_slots > 8) { // more lane slots / neighbours than registers hold: k_sweep_chroma_l stages the lanes' records in LDS
+            const uint32_t rb = 16u + 4u * (fast_slots <= 8 ? 8u : 12u);
+            chroma_rec_off = (chroma_lds + 15u) & ~15u;
+            chroma_lds = chroma_rec_off + nslot * 64u * rb;
+        }
+        chroma = ok && nslot <= (chroma_rec_off ? 8u : 4u) && chroma_lds <= kLdsBudget;
     }
     // value-parallel direct form: every group pairwise, the direct path chosen, Card 9..16, whole 64-chain scan groups
     pw4 = false;
@@ -861,7 +867,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
             f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi; f.counting = p.counting;
             f.chroma_slots = d_chroma_slots.p; f.recs_chroma = d_recs_chroma.p; f.sys_pos = d_sys_pos.p;
-            f.chroma_row = chroma_row; f.chroma_tab_off = chroma_tab_off; f.chroma_wpb = chroma_wpb; f.chroma_hist_off = chroma_hist_off;
+            f.chroma_row = chroma_row; f.chroma_tab_off = chroma_tab_off; f.chroma_wpb = chroma_wpb; f.chroma_hist_off = chroma_hist_off; f.chroma_rec_off = chroma_rec_off;
             const uint64_t head = std::min<uint64_t>(left, (sys_n_free - step % sys_n_free) % sys_n_free);
             if (head) { sys_generic(head); left -= head; }
             while (left >= sys_n_free) {

@@ -153,6 +153,131 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
     }
 }
 
+// The same sweep for models with more lane slots or neighbours than fit registers (Segmentation_11: 7 lane slots, 8 neighbours;
+// any model after a collapse): the lane slots' records -- {own byte, rank, table address, position; SLOTS x (neighbour byte |
+// 4 * multiplier << 16)} -- are staged ONCE per block in LDS, [slot][lane], and read back per update (three 16-byte reads at
+// a 48-byte lane stride: conflict-free); only the draws of the current 4 sweeps and the ones counters stay in registers.
+template <int SLOTS, bool COUNT> // SLOTS = 8 or 12 neighbour words per record
+__global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
+    constexpr uint32_t NSLOT = 8, RB = 16u + 4u * SLOTS;
+    extern __shared__ __align__(16) unsigned char lds[];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nthr = blockDim.x;
+    const uint32_t chain = blockIdx.x * p.chroma_wpb + wave;
+    const uint32_t variant = (blockIdx.x * p.chroma_wpb) / p.chains_per_variant;
+    const VariantDesc vd = p.variants[variant];
+    const uint32_t tab = lds_addr_c(lds) + p.chroma_tab_off;
+    {
+        const uint32_t n4 = (vd.cpt_len + 3u) >> 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
+        uint4 *dst = reinterpret_cast<uint4 *>(lds + p.chroma_tab_off);
+        for (uint32_t i = tid; i < n4; i += nthr) dst[i] = src[i];
+        const uint32_t wpb = p.chroma_wpb, chain0 = blockIdx.x * wpb;
+        for (uint32_t i = tid; i < p.n_vars * wpb; i += nthr) {
+            const uint32_t v = i / wpb, c = i % wpb;
+            lds[c * p.chroma_row + v] = p.state[(size_t)v * p.pitch + chain0 + c];
+        }
+        // the lane slots' records: [slot][lane], RB bytes each; an unused lane gets a record that reads and "writes" nothing
+        for (uint32_t i = tid; i < vd.csl_n * 64u; i += nthr) {
+            const uint32_t k = p.chroma_slots[(size_t)vd.csl_base * 64u + i];
+            uint32_t *d = reinterpret_cast<uint32_t *>(lds + p.chroma_rec_off + (size_t)i * RB);
+            const uint32_t kk = k == 0xffffffffu ? 0u : k;
+            const uint32_t *r = p.recs_chroma + (size_t)(vd.rec_base + kk) * 16u;
+            d[0] = r[0];
+            d[1] = k;                                   // rank in the free list, 0xffffffff = lane not in use
+            d[2] = tab + r[2];
+            d[3] = p.sys_pos[vd.free_base + kk];
+            for (uint32_t j = 0; j < (uint32_t)SLOTS; ++j) d[4 + j] = r[4 + j];
+        }
+    }
+    __syncthreads();
+    const uint32_t row = lds_addr_c(lds) + wave * p.chroma_row;
+    const uint32_t recs = lds_addr_c(lds) + p.chroma_rec_off + lane * RB;
+    const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
+    const uint64_t step0 = ((uint64_t)p.step0_hi << 32) | p.step0_lo;
+    const uint64_t sweep0 = step0 / vd.n_free;
+    const uint32_t n_sweeps = p.n_steps / vd.n_free;
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) v4u lds_u4_t;
+    uint32_t ones[NSLOT], posr[NSLOT];
+#pragma unroll
+    for (int s = 0; s < (int)NSLOT; ++s) {
+        ones[s] = 0;
+        posr[s] = (uint32_t)s < vd.csl_n ? ((lds_u4_t *)(uintptr_t)(recs + (uint32_t)s * 64u * RB))->w : 0u;
+    }
+    for (uint64_t sq = sweep0 >> 2; (sq << 2) < sweep0 + n_sweeps; ++sq) {
+        uint32_t U[NSLOT][4];
+#pragma unroll
+        for (int s = 0; s < (int)NSLOT; ++s) {
+            if ((uint32_t)s >= vd.csl_n) break;
+            const u32x4 d = philox_sys_draw(sq << 2, posr[s], gchain, p.seed_lo, p.seed_hi);
+            U[s][0] = d.x; U[s][1] = d.y; U[s][2] = d.z; U[s][3] = d.w;
+        }
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const uint64_t sweep = (sq << 2) + (uint64_t)w;
+            if (sweep < sweep0 || sweep >= sweep0 + n_sweeps) continue;
+#pragma unroll
+            for (int s = 0; s < (int)NSLOT; ++s) {
+                if ((uint32_t)s >= vd.csl_n) break;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                const uint32_t ra = recs + (uint32_t)s * 64u * RB;
+                const v4u h = *(lds_u4_t *)(uintptr_t)ra;
+                v4u sw[SLOTS / 4];
+#pragma unroll
+                for (int i = 0; i < SLOTS / 4; ++i) sw[i] = *(lds_u4_t *)(uintptr_t)(ra + 16u + 16u * (uint32_t)i);
+                uint32_t x[SLOTS];
+#pragma unroll
+                for (int i = 0; i < SLOTS; ++i) {
+                    const uint32_t wv = i % 4 == 0 ? sw[i / 4].x : i % 4 == 1 ? sw[i / 4].y : i % 4 == 2 ? sw[i / 4].z : sw[i / 4].w;
+                    x[i] = (uint32_t)*(lds_u8c_t *)(uintptr_t)(row + (wv & 0xffffu));
+                }
+                uint32_t a = h.z;
+#pragma unroll
+                for (int i = SLOTS - 1; i >= 0; --i) {
+                    const uint32_t wv = i % 4 == 0 ? sw[i / 4].x : i % 4 == 1 ? sw[i / 4].y : i % 4 == 2 ? sw[i / 4].z : sw[i / 4].w;
+                    a = mad_u16_hi_c(wv, x[i], a);
+                }
+                const uint32_t T = *(lds_u32c_t *)(uintptr_t)a;
+                const bool val = U[s][w] >= T;
+                if (h.y != 0xffffffffu) {
+                    *(lds_u8c_t *)(uintptr_t)(row + h.x) = val ? (unsigned char)1 : (unsigned char)0;
+                    if constexpr (COUNT) ones[s] += val ? 1u : 0u;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        const uint32_t wpb = p.chroma_wpb, chain0 = blockIdx.x * wpb;
+        for (uint32_t i = tid; i < p.n_vars * wpb; i += nthr) {
+            const uint32_t v = i / wpb, c = i % wpb;
+            p.state[(size_t)v * p.pitch + chain0 + c] = lds[c * p.chroma_row + v];
+        }
+    }
+    if constexpr (COUNT) {
+        uint32_t *hh = reinterpret_cast<uint32_t *>(lds + p.chroma_hist_off);
+        for (uint32_t i = tid; i < 2u * vd.n_free; i += nthr) hh[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < (int)NSLOT; ++s) {
+            if ((uint32_t)s >= vd.csl_n) break;
+            const uint32_t k = ((lds_u4_t *)(uintptr_t)(recs + (uint32_t)s * 64u * RB))->y;
+            if (k != 0xffffffffu) {
+                atomicAdd(&hh[2u * k + 1u], ones[s]);
+                atomicAdd(&hh[2u * k], n_sweeps - ones[s]);
+            }
+        }
+        __syncthreads();
+        unsigned long long *gc = p.counts + (size_t)variant * p.H;
+        for (uint32_t i = tid; i < vd.n_free; i += nthr) {
+            const uint32_t v = p.free_vars[vd.free_base + i];
+            const uint32_t ho = p.cprogs[vd.cprog_base + p.cprog_off[vd.cprogoff_base + v] + 1u];
+            if (hh[2u * i]) atomicAdd(&gc[ho], (unsigned long long)hh[2u * i]);
+            if (hh[2u * i + 1u]) atomicAdd(&gc[ho + 1u], (unsigned long long)hh[2u * i + 1u]);
+        }
+    }
+}
+
 template <int NSLOT, int SLOTS>
 static hipError_t launch_chroma_t(const FastParams &p, uint32_t blocks, uint32_t lds, hipStream_t s) {
     auto go = [&](auto kern) -> hipError_t {
@@ -164,7 +289,22 @@ static hipError_t launch_chroma_t(const FastParams &p, uint32_t blocks, uint32_t
     return p.counting ? go(&k_sweep_chroma<NSLOT, SLOTS, true>) : go(&k_sweep_chroma<NSLOT, SLOTS, false>);
 }
 
+template <int SLOTS>
+static hipError_t launch_chroma_l_t(const FastParams &p, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(blocks), dim3(64u * p.chroma_wpb), lds, s, p);
+        return hipGetLastError();
+    };
+    return p.counting ? go(&k_sweep_chroma_l<SLOTS, true>) : go(&k_sweep_chroma_l<SLOTS, false>);
+}
+
 hipError_t launch_sweep_chroma(const FastParams &p, int n_lane_slots, int slots, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    if (p.chroma_rec_off) { // records staged in LDS: up to 8 lane slots, 12 neighbours
+        if (n_lane_slots > 8 || slots > 12) return hipErrorInvalidValue;
+        return slots <= 8 ? launch_chroma_l_t<8>(p, blocks, lds, s) : launch_chroma_l_t<12>(p, blocks, lds, s);
+    }
     if (n_lane_slots > 4 || slots > 8) return hipErrorInvalidValue;
     if (n_lane_slots <= 2) return slots <= 4 ? launch_chroma_t<2, 4>(p, blocks, lds, s) : launch_chroma_t<2, 8>(p, blocks, lds, s);
     return slots <= 4 ? launch_chroma_t<4, 4>(p, blocks, lds, s) : launch_chroma_t<4, 8>(p, blocks, lds, s);

@@ -116,7 +116,7 @@ int gr_error_suite(int32_t n_vars, const int32_t *card, const int32_t *fixed1, c
                                             variable order[t mod n] -- colour class by colour class, ascending id inside a class -- so updates
                                             per chain still count single-variable updates and n of them are one sweep.  The stationary law is the
                                             model's, like the random scan's; the chain's law is NOT the reference's (off by default).
-                                            Binary memoisable models with small blankets run k_sweep_chroma: one wavefront per chain, one lane per
+                                            Binary memoisable models (up to 8 lane slots of 64 variables per colour chunk, 12 neighbours) run k_sweep_chroma / k_sweep_chroma_l: one wavefront per chain, one lane per
                                             variable of a colour class, all of a class updated side by side -- full occupancy from 4 096 chains up.
                                             Not combinable with GR_FLAG_SCAN_PER_CHAIN; gr_advance_chain / gr_advance_window keep working through
                                             gr_advance_window only (the stopping rule of AdvanceChain is a property of the random scan). */

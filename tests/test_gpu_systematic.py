@@ -30,8 +30,11 @@ def _gm(pm):
     ("Grids_11.uai", False, 128, 13, 457, 0, 9),            # chromatic kernel; the launches start and end inside a sweep
     ("Grids_11.uai", False, 64, 250, 230, g.GR_FLAG_DIRECT, 0),  # generic kernel, systematic mode
     ("ObjectDetection_13.uai", False, 64, 7, 150, 0, 0),    # Card 16
-    ("Pedigree_11.uai", True, 64, 5, 700, 0, 0),            # evidence, Card 3, arity 4
+    ("Pedigree_11.uai", True, 64, 5, 700, 0, 9),            # with its evidence every selectable variable is binary: records in LDS
+    ("Pedigree_11.uai", False, 64, 5, 300, 0, 0),           # Card 3, arity 4: generic kernel
     ("grid3x3", False, 192, 3, 100, 0, 9),
+    ("Segmentation_11.uai", False, 64, 9, 500, 0, 9),      # 228 variables, more lane slots than registers hold: records staged in LDS (k_sweep_chroma_l)
+    ("Promedus_11.uai", True, 64, 5, 900, 0, 0),           # evidence, arity 3: more than 8 lane slots -> generic kernel
     ("mixed_evidence", False, 64, 2, 41, 0, 0),
 ])
 def test_systematic_sweep_bitwise_vs_emulator(res_dir, name, ev, chains, burn, steps, flags, path):
@@ -54,9 +57,18 @@ def test_systematic_sweep_bitwise_vs_emulator(res_dir, name, ev, chains, burn, s
     assert s.TotalSampleCount() == chains * (steps + len(order) + 1)
 
 
-@pytest.mark.parametrize("name,chains", [("Grids_13.uai", 4096), ("Grids_11.uai", 8192)])
+@pytest.mark.parametrize("name,chains", [("Grids_13.uai", 4096), ("Grids_11.uai", 8192), ("Segmentation_11.uai", 2048)])
 def test_chromatic_kernel_equals_generic_systematic(res_dir, name, chains):
     m = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    if name.startswith("Seg"):
+        out = []
+        for flags in (SYS, SYS | g.GR_FLAG_DIRECT):
+            s = g.HIPChains(m, chains, seed=5, flags=flags)
+            s.BurnIn(1234); s.Advance(228 * 9 + 11); s.Advance(228)
+            out.append((s.info()["path"], s.counts(), s.checkpoint()["states"]))
+        assert out[0][0] == 9 and out[1][0] == 0
+        assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+        return
     out = []
     for flags in (SYS, SYS | g.GR_FLAG_DIRECT):
         s = g.HIPChains(m, chains, seed=5, flags=flags)
