@@ -55,6 +55,7 @@ hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32
 // wide step-parallel form (8 or 16 lanes per chain; sweep_bin.hip, GR_PAR4_PART 5): its own scan plan + sweep, burn-in / counting only
 hipError_t launch_scan_plan_wide(const FastParams &p, int lpc, hipStream_t s);
 hipError_t launch_sweep_wide(const FastParams &p, int lpc, int slots, uint32_t groups, uint32_t lds, hipStream_t s);
+hipError_t launch_sweep_wide_dense(const FastParams &p, uint32_t groups, uint32_t lds, hipStream_t s); // 8 lanes, <= 64 registers (experiment)
 // chromatic form of the systematic scan (sweep_chroma.hip): one wavefront per chain, blocks of 64 * p.chroma_wpb lanes
 hipError_t launch_sweep_chroma(const FastParams &p, int n_lane_slots, int slots, uint32_t blocks, uint32_t lds, hipStream_t s);
 // step-parallel form of the direct conditional (sweep_dir4.hip): Card <= 4, arity <= 4, 64-chain blocks of 256 lanes

@@ -263,6 +263,7 @@ void gr_sampler::configure() {
         for (const auto &im : image) rec_bytes += (uint64_t)im.free_vars.size() * rec_stride;
         wide_ok = fast && par && !strict_fast && par_packed && rec_bytes < (1ull << 26) && !o.block_threads &&
                   (o.fast_form == 0 || o.fast_form == 2 || o.fast_form >= 6) && par_rec_off <= kLdsBudget;
+        // (fast_form 10: experiment, see launch_sweep_wide_dense)
     }
     // systematic scan: the chromatic kernel when every group is binary + memoised with at most 4 lane slots (colour classes cut
     // into chunks of 64 variables) and 8 neighbours, all groups sweep the same number of variables, and the threshold pool fits
@@ -954,7 +955,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             // with its own copy of the tables: the first rounds of an adaptive run); 8 lanes while 8 x groups <= 4 096; beyond that the
             // 4-lane form has the chip full and the wider forms' extra passes only cost
             const uint32_t fit = kLdsBudget / std::max(par_rec_off, 1u);
-            if (o.fast_form == 8) lpc = 8;
+            if (o.fast_form == 8 || o.fast_form == 10) lpc = 8;
             else if (o.fast_form == 9) lpc = 16;
             else if (o.fast_form == 0 && groups * 16u <= 4096u && (fit >= 4u || groups * 16u <= 256u * fit)) lpc = 16;
             else if (o.fast_form == 0 && groups * 8u <= 4096u) lpc = 8;
@@ -993,6 +994,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 // ... and the CUs' LDS holds all of those blocks at once (each stages its own copy of the tables)
                 f.par_spread = (act / 64u * lpc <= 1024u && (uint64_t)(act / 64u) * lpc <= 256ull * (kLdsBudget / par_rec_off)) ? 1u : 0u;
                 hip_check(launch_scan_plan_wide(f, (int)lpc, stream), "k_scan_plan_wide launch");
+                if (o.fast_form == 10 && fast_slots <= 4 && !par_tabg) { f.par_spread = 0; hip_check(launch_sweep_wide_dense(f, act / 64u, par_rec_off, stream), "k_sweep_wide (dense) launch"); }
+                else
                 hip_check(launch_sweep_wide(f, (int)lpc, fast_slots, act / 64u, par_rec_off, stream), "k_sweep_wide launch");
                 step += n; left -= n; launches_last++;
                 continue;

@@ -991,8 +991,10 @@ __global__ void __launch_bounds__(256) k_scan_plan_wide(const FastParams p) {
     }
 }
 
-template <int LPC, int SLOTS, int MODE, int TABG> // MODE 0: burn-in, 1: count
-__global__ void __launch_bounds__(64 * LPC, 4) k_sweep_wide(const FastParams p) { // (4 wavefronts per SIMD: <= 128 registers)
+// DENSE (8 lanes per chain, 4-slot records, tables in LDS): records one round ahead and at most 64 registers, so that a SIMD holds 8
+// wavefronts -- 65 536 chains as 8 192 resident wavefronts (experiment: fast_form 10)
+template <int LPC, int SLOTS, int MODE, int TABG, bool DENSE = false> // MODE 0: burn-in, 1: count
+__global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const FastParams p) { // (4 wavefronts per SIMD: <= 128 registers)
     constexpr bool COUNT = MODE != 0, PACKED = true;
     constexpr uint32_t W = 64u / LPC, E = LPC / 4u;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -1046,7 +1048,7 @@ __global__ void __launch_bounds__(64 * LPC, 4) k_sweep_wide(const FastParams p) 
     // four, like k_sweep_par4); SLOTS > 4 -- ONE record ahead (two sets of one, the next round's fetched while the current round
     // runs): two sets of four 12..20-word records are 96..160 registers, and above 128 a CU holds one 512-lane block where its
     // LDS would take two (Segmentation_11, Promedus, collapsed groups).
-    constexpr bool ROUND_AHEAD = SLOTS > 4;
+    constexpr bool ROUND_AHEAD = SLOTS > 4 || DENSE;
     constexpr int NSET = ROUND_AHEAD ? 1 : 4;
     uint32_t pwA[4] = {0, 0, 0, 0}, pwB[4] = {0, 0, 0, 0};
     RecL<SLOTS, PACKED> rA[NSET], rB[NSET];
@@ -1155,6 +1157,16 @@ static hipError_t launch_wide_l(const FastParams &p, int slots, uint32_t groups,
     if (slots <= 12) return launch_wide_t<LPC, 12>(p, groups, lds, s);
     if (slots <= 16) return launch_wide_t<LPC, 16>(p, groups, lds, s);
     return hipErrorInvalidValue;
+}
+
+hipError_t launch_sweep_wide_dense(const FastParams &p, uint32_t groups, uint32_t lds, hipStream_t s) {
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, dim3(groups), dim3(512), lds, s, p);
+        return hipGetLastError();
+    };
+    return p.counting ? go(&k_sweep_wide<8, 4, 1, 0, true>) : go(&k_sweep_wide<8, 4, 0, 0, true>);
 }
 
 hipError_t launch_sweep_wide(const FastParams &p, int lpc, int slots, uint32_t groups, uint32_t lds, hipStream_t s) {
