@@ -53,6 +53,7 @@ SIGNATURES = {
     "gr_model_func_scope": (C.c_int, [vp, C.c_int, pi32]),
     "gr_model_func_table": (C.c_int, [vp, C.c_int, pd]),
     "gr_model_func_eval": (C.c_int, [vp, C.c_int, pi32, C.c_int, pd]),
+    "gr_model_systematic_order": (C.c_int, [vp, pi32, pi32, pi32]),
     "gr_solution_from_text": (vp, [C.c_char_p, C.c_size_t]),
     "gr_solution_from_file": (vp, [C.c_char_p]),
     "gr_solution_destroy": (None, [vp]),

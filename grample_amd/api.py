@@ -142,6 +142,14 @@ class Model:
         _chk(self.L.gr_model_func_table(self.ptr, f, _p(out, C.c_double)))
         return out
 
+    def systematic_order(self):
+        """(order, colour per variable) of GR_FLAG_SCAN_SYSTEMATIC for this model"""
+        n = self.n_vars
+        order, color = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        k = C.c_int32()
+        _chk(self.L.gr_model_systematic_order(self.ptr, _p(order, C.c_int32), C.byref(k), _p(color, C.c_int32)))
+        return order[: k.value].tolist(), color.tolist()
+
     def Eval(self, f, values):
         v = _i32(values)
         out = C.c_double()

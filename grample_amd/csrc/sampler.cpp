@@ -1177,6 +1177,22 @@ GR_VISIBLE int gr_model_func_eval(const gr_model *m, int f, const int32_t *value
     return guarded([&] { *out = m->m.Eval(*fn, values, n_values); });
 }
 
+GR_VISIBLE int gr_model_systematic_order(const gr_model *m, int32_t *out_order, int32_t *out_n, int32_t *out_color) {
+    return guarded([&] {
+        if (!m || !out_order || !out_n) throw Error(GR_E_INVALID, "null argument");
+        Model lm = m->m;
+        for (auto &f : lm.Funcs) Model::UseLogSpace(f);
+        const VariantImage im = CompileVariant(lm, CompileLimits{});
+        *out_n = (int32_t)im.sys_order.size();
+        std::copy(im.sys_order.begin(), im.sys_order.end(), out_order);
+        if (out_color) {
+            std::fill(out_color, out_color + lm.Vars.size(), -1);
+            for (size_t c = 0; c + 1 < im.color_off.size(); ++c)
+                for (uint32_t i = im.color_off[c]; i < im.color_off[c + 1]; ++i) out_color[im.sys_order[i]] = (int32_t)c;
+        }
+    });
+}
+
 // ============================================================== solution
 GR_VISIBLE gr_solution *gr_solution_from_text(const char *text, size_t len) {
     gr_solution *out = nullptr;

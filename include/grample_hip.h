@@ -77,6 +77,10 @@ int gr_model_func_scope(const gr_model *m, int f, int32_t *out /*[arity]*/);
 int gr_model_func_table(const gr_model *m, int f, double *out /*[tabsize]*/);
 /* Function.Eval (model/function.go:146-157): *out = NaN and GR_E_INVALID on bad input */
 int gr_model_func_eval(const gr_model *m, int f, const int32_t *values, int n_values, double *out);
+/* The sweep order of GR_FLAG_SCAN_SYSTEMATIC for this model (pure host function): the selectable variables (FixedVal < 0) by
+ * (colour, id), colours from a greedy colouring of the factor graph in ascending id.  out_order [n_vars] receives *out_n
+ * variables, out_color [n_vars] (may be NULL) the colour of every variable (-1 for evidence). */
+int gr_model_systematic_order(const gr_model *m, int32_t *out_order, int32_t *out_n, int32_t *out_color);
 
 /* ----------------------------------------------------------------- solution */
 gr_solution *gr_solution_from_text(const char *text, size_t len);    /* ReadMargSolution (uai.go:252-332) */

@@ -365,3 +365,37 @@ def test_reader_fuzz_roundtrip_and_mutations():
             assert all(0 <= v < len(cards) for v in sc)
             assert len(m.func_table(f)) == int(np.prod([cards[v] for v in sc]))
     assert rejected > 120 and accepted + rejected == 240
+
+
+def test_systematic_order_is_a_proper_colouring_on_every_fixture(res_dir):
+    """GR_FLAG_SCAN_SYSTEMATIC's sweep order (host code, no GPU): on every fixture model, with and without evidence, the order lists
+    every selectable variable once, by (colour, id); no factor holds two selectable variables of one colour (so a colour class can
+    be resampled side by side); and it equals the Python twin the GPU tests replay with (tests/emulator.py)."""
+    from tests.emulator import systematic_order
+    seen = 0
+    for f in sorted(os.listdir(res_dir)):
+        if not f.endswith(".uai"):
+            continue
+        for ev in (False, True):
+            if ev and not os.path.exists(os.path.join(res_dir, f + ".evid")):
+                continue
+            try:
+                pm = uai_py.load(res_dir, f, ev)
+                m = g.Model.NewModelFromFile(os.path.join(res_dir, f), ev)
+            except Exception:
+                continue
+            order, color = m.systematic_order()
+            free = [v for v in range(len(pm.card)) if pm.fixed[v] < 0]
+            assert sorted(order) == free
+            assert order == sorted(free, key=lambda v: (color[v], v))
+            assert all(color[v] == -1 for v in range(len(pm.card)) if pm.fixed[v] >= 0)
+            for sc in pm.scopes:
+                cs = [color[v] for v in sc if pm.fixed[v] < 0]
+                assert len(cs) == len(set(cs)), (f, ev, sc)
+            want, wcol = systematic_order(pm.card, pm.fixed, pm.scopes)
+            assert order == want
+            seen += 1
+    assert seen >= 19
+    # Grids: the checkerboard (two colours)
+    order, color = g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai")).systematic_order()
+    assert max(color) == 1 and len(order) == 100
