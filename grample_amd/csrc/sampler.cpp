@@ -841,8 +841,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         T = 256; blocks = (act + 255) / 256;
         generic(n_total);
     };
-    if (cur_log_pc) {
-        generic_small(updates); // strict mode's logged windows: the generic kernel's per-chain scan with the per-chain log
+    if (cur_log_pc && !strict_fast) {
+        generic_small(updates); // strict mode's logged windows on the direct path: the generic kernel's per-chain scan with the per-chain log
     } else if (sysscan) {
         // systematic scan: whole sweeps from a sweep boundary on the chromatic kernel, everything else (and every model that
         // kernel does not take) on the generic kernel's systematic mode -- same order, same draws, same thresholds

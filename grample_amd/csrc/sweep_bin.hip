@@ -729,7 +729,9 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
 // (DOM_SCAN_CHAIN for the variables, DOM_DRAW for the values); per-lane LDS atomics for the histogram.
 // Steps of a chain are sequential, so nothing needs re-gathering.  Bit-identical to the generic
 // kernel's strict mode (k_sweep<.., PC = true>), which handles quad-unaligned heads and tails.
-template <int SLOTS, bool PACKED, bool COUNT>
+// LOG (gr_advance_chain in strict mode): every chain executes only the first limit[chain] steps of the window (its own
+// stopping time) and logs the value of each of its updates, one byte per chain and step, [group][step][64 chains].
+template <int SLOTS, bool PACKED, bool COUNT, bool LOG = false>
 __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     // 1 or 4 wavefronts per block share the tables and records; wave 0 keeps its 64 chains in the layout's state
@@ -767,6 +769,13 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
     // latency of each step of the current quad: a lone wavefront per SIMD has nothing else to hide it with.
     u32x4 sc = philox4x32_10((uint32_t)q0, (uint32_t)(q0 >> 32), g_lo, DOM_SCAN_CHAIN + g_hi4, p.seed_lo, p.seed_hi);
     u32x4 dr = philox4x32_10((uint32_t)q0, (uint32_t)(q0 >> 32), g_lo, DOM_DRAW + g_hi4, p.seed_lo, p.seed_hi);
+    uint32_t lim = 0xffffffffu;
+    unsigned char *logp = nullptr;
+    if constexpr (LOG) {
+        const uint32_t t = p.limit[chain];
+        lim = t > p.log_off ? t - p.log_off : 0u;
+        logp = p.log + (size_t)(chain >> 6) * p.log_pitch + (size_t)p.log_off * 64u + lane;
+    }
     for (uint32_t qi = 0; qi < nq; ++qi) {
         const uint64_t qn = q0 + qi + 1u;
         const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w}, du[4] = {dr.x, dr.y, dr.z, dr.w};
@@ -793,9 +802,12 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
             else pd.template rounds<5>();
             __builtin_amdgcn_sched_barrier(0);
             const uint32_t val = (du[j] >= table_l<SLOTS, PACKED>(r[j], x, lds)) ? 1u : 0u;
-            st[r[j].h.x] = (unsigned char)val;
-            if constexpr (COUNT) {
-                __hip_atomic_fetch_add(lds_at(r[j].h.y + val * 4u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (!LOG || qi * 4u + (uint32_t)j < lim) {
+                st[r[j].h.x] = (unsigned char)val;
+                if constexpr (COUNT) {
+                    __hip_atomic_fetch_add(lds_at(r[j].h.y + val * 4u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                if constexpr (LOG) logp[(size_t)(qi * 4u + (uint32_t)j) * 64u] = (unsigned char)val;
             }
         }
         sc = u32x4{ps.c0, ps.c1, ps.c2, ps.c3};
@@ -819,6 +831,7 @@ static hipError_t launch_strict_t(const FastParams &p, uint32_t blocks, uint32_t
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds, s, p);
         return hipGetLastError();
     };
+    if (p.log && p.limit) return go(&k_sweep_strict<SLOTS, PACKED, true, true>); // logged windows always count
     return p.counting ? go(&k_sweep_strict<SLOTS, PACKED, true>) : go(&k_sweep_strict<SLOTS, PACKED, false>);
 }
 
