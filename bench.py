@@ -168,6 +168,37 @@ def other_configs(res_dir, g, device):
                     "effective_hbm_frac": ALGO_BYTES[model] * rate / 1e9 / HBM_PEAK_GBS,
                     "oracle_probe": oracle_probe(res_dir, g, model, **pk) if pk is not None else None})
         s.close()
+    out.append(adaptive_config(res_dir, g, device))
+    return out
+
+
+def adaptive_config(res_dir, g, device, rounds=34, cw=2000, start=2, step=4):
+    """BASELINE.json configs[3] as the reference RUNS it (script/experiment + sampler/adaptive.go): start with 2 chain groups, each round
+    AdvanceChain(cw) -> merge + score -> Adapt(+4 groups, each collapsing the variable AdaptSelect picks), until all 128 groups
+    of 256 chains are live.  End-to-end wall clock, everything included (table builds for the new groups, merges, selection)."""
+    import numpy as np
+    model = "Segmentation_11.uai"
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, model), True)
+    sol = g.Solution.NewSolutionFromFile(os.path.join(res_dir, model + ".MAR")).marginals()
+    t0 = time.perf_counter()
+    s = g.HIPChains(m, 128 * 256, n_variants=128, device=device, seed=42)
+    s.set_active_groups(start)
+    s.BurnIn(2000)
+    t_ac = t_adapt = t_merge = kms = 0.0
+    for _ in range(rounds):
+        t = time.perf_counter(); s.AdvanceChain(cw); t_ac += time.perf_counter() - t
+        kms += s.info()["kernel_ms_last"]
+        t = time.perf_counter(); merged, coll = g.MergeChains([s]); es = g.NewErrorSuite(m.cards(), sol, merged); t_merge += time.perf_counter() - t
+        t = time.perf_counter(); s.Adapt(step); t_adapt += time.perf_counter() - t
+    tot = time.perf_counter() - t0
+    counted = float(s.TotalSampleCount())
+    out = {"config": f"configs[3'] Segmentation_11 adaptive GibbsCollapsed as script/experiment runs it: {start} groups -> {s.active_groups()} of 256 chains, "
+                     f"{rounds} rounds of AdvanceChain({cw}) + merge + Adapt(+{step})",
+           "value": counted / tot, "unit": "counted variable-updates/s, end to end", "timing": "wall clock from sampler creation to the last Adapt",
+           "ms": tot * 1e3, "phases_ms": {"AdvanceChain": t_ac * 1e3, "sweep_kernels": kms, "merge_and_score": t_merge * 1e3, "Adapt": t_adapt * 1e3},
+           "updates": counted, "groups": s.active_groups(), "collapsed_vars": int(np.sum(coll)),
+           "hellinger_vs_MAR": {"mean": es["MeanHellinger"], "max": es["MaxHellinger"], "mean_abs_err": es["MeanMeanAbsError"]}}
+    s.close()
     return out
 
 
