@@ -21,6 +21,7 @@ struct VariantDesc {
     uint32_t dent_base, dent_len; // 16-byte units, into the factor entries of the step-parallel direct form (k_sweep_dir4)
     uint32_t vprog_base;   // words, into vprogs (value-parallel pairwise programs, k_sweep_pw4); vprog_off shares progoff_base
     uint32_t csl_base, csl_n; // k_sweep_chroma: first lane slot of this group (64 entries each) in chroma_slots, number of lane slots
+    uint32_t zero_row;     // floats from views_base: the group's all-zero view row (what continuation entries of k_sweep_dir4's chained form load)
 };
 
 struct SweepParams {

@@ -59,7 +59,7 @@ hipError_t launch_sweep_wide_dense(const FastParams &p, uint32_t groups, uint32_
 // chromatic form of the systematic scan (sweep_chroma.hip): one wavefront per chain, blocks of 64 * p.chroma_wpb lanes
 hipError_t launch_sweep_chroma(const FastParams &p, int n_lane_slots, int slots, uint32_t blocks, uint32_t lds, hipStream_t s);
 // step-parallel form of the direct conditional (sweep_dir4.hip): Card <= 4, arity <= 4, 64-chain blocks of 256 lanes
-hipError_t launch_sweep_dir4(const FastParams &p, int max_card, bool views_in_lds, bool entries_in_lds, uint32_t blocks, uint32_t lds, hipStream_t s);
+hipError_t launch_sweep_dir4(const FastParams &p, int max_card, bool views_in_lds, bool entries_in_lds, bool chained, uint32_t blocks, uint32_t lds, hipStream_t s);
 constexpr uint32_t kParStateStride = 80; // must match kParStride in sweep_bin.hip
 
 } // namespace gr

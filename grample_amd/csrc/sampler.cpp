@@ -177,6 +177,17 @@ struct gr_sampler {
     uint32_t pw4_hist_off = 0, pw4_lds = 0;
     bool dir4 = false;                // step-parallel form of the direct conditional (k_sweep_dir4): Card <= 4, arity <= 4, blankets too large to memoise
     bool dir4_vlds = false, dir4_elds = false; // ... with the view tables / the factor entries staged in LDS
+    bool dir4_chain = false;          // ... with chained factor entries (a factor of arity > 4 or with strides past 16 bits: collapse factors)
+    // factor entries of variable v's list in the form this sampler uses: one per factor, or one per pair of other scope variables
+    uint32_t dir4_entries(const VariantImage &im, uint32_t v) const {
+        const uint32_t *pg = im.prog.data() + im.prog_off[v];
+        const uint32_t nf = pg[0] >> 16;
+        if (!dir4_chain) return nf;
+        uint32_t n = 0;
+        const uint32_t *q = pg + 2;
+        for (uint32_t f = 0; f < nf; ++f) { n += std::max(1u, (q[1] + 1u) / 2u); q += 2 + 2 * q[1]; }
+        return n;
+    }
     uint32_t dir_hist_off = 0, dir_view_off = 0, dir_ent_off = 0, dir_lds = 0, dir_slots = 0;
     DevBuf<uint32_t> d_dhdr, d_dent;  // ... its step headers (32 bytes per selectable variable) and factor entries (16 bytes per factor)
     DevBuf<unsigned char> d_log;        // draw log of gr_advance_chain windows: kept between calls (hundreds of MB: allocating and
@@ -331,12 +342,17 @@ void gr_sampler::configure() {
         bool ok = true;
         uint32_t views_max = 0, ent_max = 0;
         dir_slots = 1;
+        // a factor with more than 3 other scope variables, or a view stride past 16 bits (a collapse factor: up to 12
+        // variables, up to 2^23 entries), takes the chained entry form: two others with 32-bit strides per entry, the
+        // partial offsets of a factor's entries added up along the chain
+        dir4_chain = false;
+        for (const auto &im : image) dir4_chain = dir4_chain || im.max_others > 3u || (uint64_t)im.max_view_stride * 4u >= 65536u;
         for (const auto &im : image) {
-            ok = ok && im.max_others <= 3u && (uint64_t)im.max_view_stride * 4u < 65536u && im.max_neighbours <= 255u;
+            ok = ok && im.max_neighbours <= 255u && (uint64_t)im.views.size() * 4u < (1ull << 32);
             views_max = std::max<uint32_t>(views_max, (uint32_t)im.views.size());
             dir_slots = std::max(dir_slots, im.max_neighbours);
             uint32_t n_ent = 0; // factor entries, every selectable variable's list padded to a multiple of 4
-            for (uint32_t v : im.free_vars) n_ent += ((im.prog[im.prog_off[v]] >> 16) + 3u) & ~3u;
+            for (uint32_t v : im.free_vars) n_ent += (dir4_entries(im, v) + 3u) & ~3u;
             ent_max = std::max(ent_max, n_ent);
         }
         dir_hist_off = ((uint32_t)n_vars * kParStateStride + 15u) & ~15u;
@@ -346,7 +362,7 @@ void gr_sampler::configure() {
         // idle vector-memory path serves them better from L1/L2 (CSP_13: 1.85e10 with the views in LDS, 2.93e10 without).
         const uint32_t need = std::min<uint32_t>((o.n_chains / 64u + 255u) / 256u, 2u);
         const uint32_t with_views = dir_view_off + views_max * 4u;
-        dir4_vlds = max_card <= 2 && with_views <= kLdsBudget && kLdsBudget / with_views >= need;
+        dir4_vlds = !dir4_chain && max_card <= 2 && with_views <= kLdsBudget && kLdsBudget / with_views >= need;
         dir_ent_off = dir4_vlds ? with_views : dir_view_off;
         const uint32_t with_ent = dir_ent_off + ent_max * 16u;
         dir4_elds = with_ent <= kLdsBudget && kLdsBudget / with_ent >= need;
@@ -579,6 +595,7 @@ void gr_sampler::rebuild() {
         vd.progoff_base = (uint32_t)prog_off.size();
         vd.views_base = (uint32_t)views.size();
         vd.views_len = (uint32_t)im.views.size();
+        vd.zero_row = im.zero_row;
         vd.free_base = (uint32_t)freev.size();
         vd.n_free = (uint32_t)im.free_vars.size();
         vd.cprog_base = (uint32_t)cprogs.size();
@@ -722,13 +739,34 @@ void gr_sampler::rebuild() {
             const uint32_t vbase = dir4_vlds ? dir_view_off : 0u; // views staged in LDS: entries carry absolute LDS addresses
             for (uint32_t v : im.free_vars) {
                 const uint32_t *pg = im.prog.data() + im.prog_off[v];
-                const uint32_t C = pg[0] & 0xffu, nf = pg[0] >> 16, n_ent = (nf + 3u) & ~3u;
+                const uint32_t C = pg[0] & 0xffu, nf = pg[0] >> 16, n_ent = (dir4_entries(im, v) + 3u) & ~3u;
                 // entries staged in LDS: absolute LDS address of the variable's list; else byte offset into the entry pool
                 const uint32_t eoff = dir4_elds ? dir_ent_off + ((uint32_t)(ent.size() / 4u) - h_variants[g].dent_base) * 16u : (uint32_t)ent.size() * 4u;
                 const uint32_t h8[8] = {v * kParStateStride, dir_hist_off + pg[1] * 4u, eoff, n_ent | (C << 16), 0, 0, 0, 0};
                 hdr.insert(hdr.end(), h8, h8 + 8);
                 const uint32_t *q = pg + 2;
                 const uint32_t own = v * kParStateStride;
+                if (dir4_chain) {
+                    // {view byte offset | 1 = continuation, row1 | row2 << 16, stride1, stride2 (bytes)}: a factor's others two per
+                    // entry; a continuation entry hands its partial offset on to the next one and loads the all-zero row itself
+                    uint32_t made = 0;
+                    for (uint32_t f = 0; f < nf; ++f) {
+                        const uint32_t no = q[1], ne = std::max(1u, (no + 1u) / 2u);
+                        for (uint32_t e = 0; e < ne; ++e) {
+                            uint32_t row[2] = {own, own}, st[2] = {0, 0};
+                            for (uint32_t k = 0; k < 2 && 2 * e + k < no; ++k) { row[k] = q[2 + 2 * (2 * e + k)] * kParStateStride; st[k] = q[3 + 2 * (2 * e + k)] * 4u; }
+                            const bool last = e + 1 == ne;
+                            ent.push_back(last ? vbase + q[0] * 4u : 1u);
+                            ent.push_back(row[0] | (row[1] << 16));
+                            ent.push_back(st[0]);
+                            ent.push_back(st[1]);
+                        }
+                        made += ne;
+                        q += 2 + 2 * no;
+                    }
+                    for (; made < n_ent; ++made) { ent.push_back(vbase + im.zero_row * 4u); ent.push_back(own | (own << 16)); ent.push_back(0); ent.push_back(0); }
+                    continue;
+                }
                 for (uint32_t f = 0; f < n_ent; ++f) {
                     uint32_t toff = im.zero_row, row[3] = {own, own, own}, st[3] = {0, 0, 0}; // padding: the all-zero row, stride 0
                     if (f < nf) {
@@ -909,7 +947,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             f.n_steps = n;
             f.log = cur_log; f.log_pitch = cur_log_pitch; f.log_off = (uint32_t)(step - cur_log_step0); f.limit = cur_limit; f.log_vals = cur_log_vals;
             hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
-            hip_check(launch_sweep_dir4(f, max_card, dir4_vlds, dir4_elds, act / 64u, dir_lds, stream), "k_sweep_dir4 launch");
+            hip_check(launch_sweep_dir4(f, max_card, dir4_vlds, dir4_elds, dir4_chain, act / 64u, dir_lds, stream), "k_sweep_dir4 launch");
             step += n; left -= n; launches_last++;
         }
         if (left) generic_small(left);

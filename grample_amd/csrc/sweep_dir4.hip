@@ -42,8 +42,13 @@ __device__ __forceinline__ lds_u32d_t *lds_at_d(uint32_t addr) { return (lds_u32
 // scope variables and their byte strides in the view table; unused slots name the variable's own row with stride 0.
 // VLDS / ELDS: the group's view tables / factor entries are staged in LDS (else read from global memory through L1/L2).
 // MODE 0: burn-in, 1: count, 2: count + draw log and per-group stopping time (gr_advance_chain; SweepParams::log / limit)
-template <int MAXC, bool VLDS, bool ELDS, int MODE>
+// CHAIN: chained entries {view byte offset | 1 = continuation, row1 | row2 << 16, stride1, stride2} -- two other scope
+// variables with 32-bit byte strides per entry.  A continuation entry adds its partial offset to the next entry of the list
+// and loads the group's all-zero row itself, so a factor of any arity still contributes ONE view row, at its place in
+// Model.Funcs order (a collapse factor: up to 12 variables and 2^23 entries, gibbs-collapsed.go:93 / function.go:59).
+template <int MAXC, bool VLDS, bool ELDS, int MODE, bool CHAIN = false>
 __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
+    static_assert(!(CHAIN && VLDS), "chained entries address the view pool in global memory");
     constexpr bool COUNT = MODE != 0, LOG = MODE == 2;
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -83,6 +88,7 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
     const unsigned char *ent_g = reinterpret_cast<const unsigned char *>(p.dent);
     const unsigned char *views_g = reinterpret_cast<const unsigned char *>(p.views + vd.views_base);
     const uint32_t *gplan_w = p.plan + (size_t)blockIdx.x * p.plan_pitch + j;
+    const uint32_t zrow = vd.zero_row * 4u;
     const bool tail = (lane & 15u) == 15u;
     // draw log: one row per wavefront (the 16 chains of a step slot), log_vals bytes per step -- the number of ones, or one
     // count per value; a group executes only the first `lim` steps of the window (its own AdvanceChain stopping time)
@@ -122,6 +128,7 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
         float w[MAXC];
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) w[i] = 0.f;
+        uint32_t carry = 0; // CHAIN: partial view offset handed over from the last entry of the previous trip
         // four factors per trip: their entries, then their 12 neighbour bytes, then their 4 view rows are each requested
         // together (one memory round trip per stage and trip instead of three per factor); summed in factor order
         for (uint32_t f = 0; f < nmax; f += 4) {
@@ -133,10 +140,22 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
                     else e[i] = *reinterpret_cast<const uint4 *>(ent_g + h.z + 16u * (f + (uint32_t)i));
                 }
                 uint32_t off[4];
+                if constexpr (CHAIN) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t x1 = lds_c[e[i].y & 0xffffu], x2 = lds_c[e[i].y >> 16], x3 = lds_c[e[i].z & 0xffffu];
-                    off[i] = e[i].x + __umul24(x1, e[i].z >> 16) + __umul24(x2, e[i].w & 0xffffu) + __umul24(x3, e[i].w >> 16);
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t x1 = lds_c[e[i].y & 0xffffu], x2 = lds_c[e[i].y >> 16];
+                        off[i] = (e[i].x & ~1u) + x1 * e[i].z + x2 * e[i].w + carry;
+                        carry = (e[i].x & 1u) ? off[i] : 0u;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (e[i].x & 1u) off[i] = zrow;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const uint32_t x1 = lds_c[e[i].y & 0xffffu], x2 = lds_c[e[i].y >> 16], x3 = lds_c[e[i].z & 0xffffu];
+                        off[i] = e[i].x + __umul24(x1, e[i].z >> 16) + __umul24(x2, e[i].w & 0xffffu) + __umul24(x3, e[i].w >> 16);
+                    }
                 }
                 if constexpr (MAXC <= 2) {
                     float2 r[4];
@@ -250,7 +269,7 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
     }
 }
 
-template <int MAXC, bool VLDS, bool ELDS>
+template <int MAXC, bool VLDS, bool ELDS, bool CHAIN = false>
 static hipError_t launch_dir4_t(const FastParams &p, uint32_t blocks, uint32_t lds, hipStream_t s) {
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -258,13 +277,14 @@ static hipError_t launch_dir4_t(const FastParams &p, uint32_t blocks, uint32_t l
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
         return hipGetLastError();
     };
-    return !p.counting ? go(&k_sweep_dir4<MAXC, VLDS, ELDS, 0>) : p.log ? go(&k_sweep_dir4<MAXC, VLDS, ELDS, 2>) : go(&k_sweep_dir4<MAXC, VLDS, ELDS, 1>);
+    return !p.counting ? go(&k_sweep_dir4<MAXC, VLDS, ELDS, 0, CHAIN>) : p.log ? go(&k_sweep_dir4<MAXC, VLDS, ELDS, 2, CHAIN>) : go(&k_sweep_dir4<MAXC, VLDS, ELDS, 1, CHAIN>);
 }
 
-hipError_t launch_sweep_dir4(const FastParams &p, int max_card, bool views_in_lds, bool entries_in_lds, uint32_t blocks, uint32_t lds, hipStream_t s) {
-    if (max_card > 4) return hipErrorInvalidValue;
+hipError_t launch_sweep_dir4(const FastParams &p, int max_card, bool views_in_lds, bool entries_in_lds, bool chained, uint32_t blocks, uint32_t lds, hipStream_t s) {
+    if (max_card > 4 || (chained && views_in_lds)) return hipErrorInvalidValue;
     auto pick = [&](auto mc) -> hipError_t {
         constexpr int MC = decltype(mc)::value;
+        if (chained) return entries_in_lds ? launch_dir4_t<MC, false, true, true>(p, blocks, lds, s) : launch_dir4_t<MC, false, false, true>(p, blocks, lds, s);
         if (views_in_lds) return entries_in_lds ? launch_dir4_t<MC, true, true>(p, blocks, lds, s) : launch_dir4_t<MC, true, false>(p, blocks, lds, s);
         return entries_in_lds ? launch_dir4_t<MC, false, true>(p, blocks, lds, s) : launch_dir4_t<MC, false, false>(p, blocks, lds, s);
     };

@@ -37,11 +37,19 @@ def rows():
                 out.append({"model": f, "evidence": ev, "error": str(e)[:60]})
                 continue
             for chains in CHAINS:
-                for groups, flags, tag in ((1, 0, ""), (1, g.GR_FLAG_SCAN_SYSTEMATIC, "systematic")):
-                    if tag and chains not in (4096, 65536):
+                for groups, flags, tag in ((1, 0, ""), (1, g.GR_FLAG_SCAN_SYSTEMATIC, "systematic"), (16, 0, "collapsed")):
+                    if tag == "systematic" and chains not in (4096, 65536):
+                        continue
+                    if tag == "collapsed" and (chains != 32768 or ev):
                         continue
                     try:
                         s = g.HIPChains(m, chains, n_variants=groups, flags=flags)
+                        if tag == "collapsed":  # every group but the first collapses one variable (the adaptive sampler's shape); models where no blanket fits keep theirs
+                            try:
+                                for k in range(1, groups):
+                                    s.Collapse(k, -1)
+                            except g.GrError:
+                                pass
                         s.BurnIn(64)  # the lanes per chain are chosen per launch
                         i = s.info()
                         out.append({"model": f, "evidence": ev, "chains": chains, "scan": tag or "random", "path": i["path"], "kernel": PATH.get(i["path"], "?"),

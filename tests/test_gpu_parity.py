@@ -379,6 +379,28 @@ def test_step_parallel_direct_form_equals_generic(res_dir, name):
     assert int(out[0][1].sum()) == 1024 * 275
 
 
+@pytest.mark.parametrize("name,groups", [("CSP_13.uai", 4), ("CSP_12.uai", 2), ("Alchemy_11.uai", 4), ("Pedigree_11.uai", 2)])
+def test_step_parallel_direct_form_with_collapse_factors(res_dir, name, groups):
+    """Collapsed chain groups of the dense models stay on k_sweep_dir4 (path 8): a collapse factor (up to 12 scope variables,
+    32-bit view strides) is walked as CHAINED factor entries, two scope variables per entry, and still contributes one view
+    row at its place in Model.Funcs order -- the same process as the generic direct kernel, bit for bit, plain windows and
+    AdvanceChain's logged ones."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    out = []
+    for flags in (0, g.GR_FLAG_DIRECT):
+        s = g.HIPChains(m, 256 * groups, n_variants=groups, seed=29, chain_offset=(1 << 33) + 64, flags=flags)
+        cv = [s.Collapse(k, -1)[0] for k in range(1, groups)]  # group 0 keeps the base model
+        s.BurnIn(45); s.Advance(211); s.Advance(64)
+        path = s.info()["path"]
+        L = s.AdvanceChain(40)
+        a, b, cw = s.window_halves()
+        out.append((path, cv, s.counts(), s.checkpoint()["states"], L, a, b))
+        s.close()
+    assert out[0][0] == 8 and out[1][0] == 0 and out[0][1] == out[1][1] and len(set(out[0][1])) >= 1
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][3], out[1][3])
+    assert out[0][4] == out[1][4] and np.array_equal(out[0][5], out[1][5]) and np.array_equal(out[0][6], out[1][6])
+
+
 def test_value_parallel_form_equals_chain_per_lane(res_dir):
     """k_sweep_pw4 (4 lanes per chain, one per block of 4 values; path 6) and the chain-per-lane direct kernel (path 0) are
     the same process bit for bit: ObjectDetection_13 and random pairwise models with Card 2..16, evidence and floor-heavy
