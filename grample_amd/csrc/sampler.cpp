@@ -175,7 +175,7 @@ struct gr_sampler {
     bool stg = false;                 // chain state stays in global memory (k_sweep<.., STG>): models whose state does not fit LDS
     bool pw4 = false;                 // value-parallel form of the direct path (k_sweep_pw4): pairwise, 8 < Card <= 16
     uint32_t pw4_hist_off = 0, pw4_lds = 0;
-    bool dir4 = false;                // step-parallel form of the direct conditional (k_sweep_dir4): Card <= 4, arity <= 4, blankets too large to memoise
+    bool dir4 = false;                // step-parallel form of the direct conditional (k_sweep_dir4): Card <= 4, blankets too large to memoise
     bool dir4_vlds = false, dir4_elds = false; // ... with the view tables / the factor entries staged in LDS
     bool dir4_chain = false;          // ... with chained factor entries (a factor of arity > 4 or with strides past 16 bits: collapse factors)
     // factor entries of variable v's list in the form this sampler uses: one per factor, or one per pair of other scope variables
@@ -328,8 +328,9 @@ void gr_sampler::configure() {
         // one on half of the SIMDs), still 1.5x at 262 144 (fewer table bytes in flight per wavefront) -- so: whenever it fits
         pw4 = pw4_lds <= kLdsBudget;
     }
-    // step-parallel direct form: blankets too large to memoise, at most 4 values per variable, arity <= 4, everything a
-    // 16-byte factor entry has to hold fits 16 bits (state rows 80 bytes apart: up to 819 variables; byte strides < 64 KiB)
+    // step-parallel direct form: blankets too large to memoise, at most 4 values per variable, state rows (80 bytes apart)
+    // that fit the 16-bit fields of a factor entry: up to 819 variables.  Arity <= 4 with byte strides < 64 KiB: one entry
+    // per factor; otherwise (collapse factors) the chained entry form
     dir4 = false;
     // (GR_FLAG_DIRECT keeps the generic kernel: it is the cross-check every other form is compared with)
     // ... and models that are memoisable but not binary (the generic memoised kernel is chain-per-lane too: Pedigree_11 without

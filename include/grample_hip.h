@@ -247,7 +247,7 @@ typedef struct gr_sampler_info {
     uint32_t lds_bytes;
     uint32_t path;          /* 0 = direct conditional, 1 = memoised conditional tables, 2 = memoised + planned scan (binary fast path), 3 = same, 4 lanes per chain, 5 = strict per-chain scan on memoised tables,
                                6 = direct conditional, value-parallel (4 lanes per chain, pairwise models with 8 < Card <= 16);
-                               8 = direct conditional, step-parallel (4 lanes per chain: Card <= 4, arity <= 4, blankets too large to memoise);
+                               8 = direct conditional, step-parallel (4 lanes per chain: Card <= 4, blankets too large to memoise; collapse factors as chained entries);
                                9 = systematic (chromatic) scan on memoised tables, one wavefront per chain (GR_FLAG_SCAN_SYSTEMATIC);
                                + 16 when the chain state stays in global memory (paths 0 and 1 only) */
     uint32_t max_card;
