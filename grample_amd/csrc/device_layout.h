@@ -123,6 +123,8 @@ struct FastParams {
     const uint32_t *chroma_slots;
     const uint32_t *recs_chroma;
     const uint32_t *sys_pos;     // position in the sweep order of every entry of the free list (the draw stream's key)
+    const uint32_t *sys_rank;    // the inverse: free-list index of every position of the sweep order.  Non-null = the plan-based
+                                 // kernels (k_scan_plan + k_sweep_dir4) run the systematic scan
     uint32_t chroma_row, chroma_tab_off, chroma_wpb, chroma_hist_off;
     uint32_t chroma_rec_off;     // 0 = the lanes' records live in registers (k_sweep_chroma); else their LDS offset (k_sweep_chroma_l)
     uint32_t par_tab_words;      // k_sweep_par4 with tab_global: the first par_tab_words words of every group's pool are staged in LDS all
@@ -151,6 +153,7 @@ struct ScanArgs {
     uint32_t step0_lo, step0_hi; // first step of the window
     const uint32_t *hoff;        // [n_vars + 1] histogram offset of every variable (prefix sum of Card)
     uint32_t H;
+    const uint32_t *sys_order;   // GR_FLAG_SCAN_SYSTEMATIC: the sweep order (free_base layout); null = random scan
 };
 
 } // namespace gr

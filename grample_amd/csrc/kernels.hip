@@ -536,6 +536,15 @@ __global__ void __launch_bounds__(256) k_scan_vars(const ScanArgs a, uint32_t n_
     const ScanReplay sr(a, g);
     const uint64_t q = ((((uint64_t)a.step0_hi << 32) | a.step0_lo) >> 2) + qi;
     uint32_t v[4];
+    if (a.sys_order) { // systematic scan: step t updates sys_order[t mod n]
+        const uint32_t *ord = a.sys_order + (sr.freev - a.free_vars);
+        uint32_t pos = (uint32_t)((q << 2) % sr.n_free);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = ord[pos];
+            if (++pos == sr.n_free) pos = 0;
+        }
+    } else
     sr.quad(q, v);
     reinterpret_cast<uint2 *>(out)[(size_t)g * pitch_quads + qi] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
 }

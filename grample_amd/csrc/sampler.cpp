@@ -166,7 +166,7 @@ struct gr_sampler {
     bool sysscan = false;             // GR_FLAG_SCAN_SYSTEMATIC
     bool chroma = false;              // ... on k_sweep_chroma (binary memoised, few lane slots); else the generic kernel's systematic mode
     uint32_t chroma_row = 0, chroma_tab_off = 0, chroma_hist_off = 0, chroma_rec_off = 0, chroma_lds = 0, chroma_nslot = 0, sys_n_free = 0, chroma_wpb = 4;
-    DevBuf<uint32_t> d_sys_order, d_sys_pos, d_chroma_slots, d_recs_chroma;
+    DevBuf<uint32_t> d_sys_order, d_sys_pos, d_sys_rank, d_chroma_slots, d_recs_chroma;
     bool no_wide = false;             // fast_form 3: every automatic choice, but never the wide form (measurements)
     bool wide_ok = false;             // ... the 8 / 16 lanes-per-chain form (k_sweep_wide) may take its place when wavefronts are what a launch lacks
     uint32_t lpc_last = 4;            // lanes per chain of the last step-parallel launch (gr_sampler_get_info)
@@ -177,6 +177,7 @@ struct gr_sampler {
     uint32_t pw4_hist_off = 0, pw4_lds = 0;
     bool dir4 = false;                // step-parallel form of the direct conditional (k_sweep_dir4): Card <= 4, blankets too large to memoise
     bool dir4_vlds = false, dir4_elds = false; // ... with the view tables / the factor entries staged in LDS
+    bool sys_wide() const { return sysscan && !chroma && fast && par && wide_ok && !no_wide && !strict_fast && (o.fast_form == 0 || o.fast_form == 8 || o.fast_form == 9); } // the systematic scan on k_sweep_wide
     bool dir4_chain = false;          // ... with chained factor entries (a factor of arity > 4 or with strides past 16 bits: collapse factors)
     // factor entries of variable v's list in the form this sampler uses: one per factor, or one per pair of other scope variables
     uint32_t dir4_entries(const VariantImage &im, uint32_t v) const {
@@ -320,7 +321,7 @@ void gr_sampler::configure() {
     pw4 = false;
     bool all_pw = true;
     for (const auto &im : image) all_pw = all_pw && im.pairwise;
-    if (all_pw && !fast && !cpt && !stg && max_card > 8 && max_card <= 16 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE | GR_FLAG_SCAN_SYSTEMATIC)) &&
+    if (all_pw && !fast && !cpt && !stg && max_card > 8 && max_card <= 16 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE)) &&
         o.fast_form != 1 && (o.n_chains % 64u) == 0 && (o.n_variants == 1 || cpv % 64u == 0) && !o.block_threads) {
         pw4_hist_off = ((uint32_t)n_vars * 64u + 15u) & ~15u;
         pw4_lds = pw4_hist_off + 4u * (uint32_t)H * 4u;
@@ -337,7 +338,7 @@ void gr_sampler::configure() {
     // evidence 3.5e10 there, 9.3e10 here), unless they are so small that most quads are one dependency chain (sample.uai)
     uint32_t nfree_min = 0xffffffffu;
     for (const auto &im : image) nfree_min = std::min<uint32_t>(nfree_min, (uint32_t)im.free_vars.size());
-    if (!fast && (!cpt || nfree_min >= 16u) && !stg && !pw4 && max_card <= 4 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE | GR_FLAG_DIRECT | GR_FLAG_SCAN_SYSTEMATIC)) &&
+    if (!fast && (!cpt || nfree_min >= 16u) && !stg && !pw4 && max_card <= 4 && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SEQUENTIAL | GR_FLAG_CHAIN_PER_LANE | GR_FLAG_DIRECT)) && !(sysscan && chroma) &&
         o.fast_form != 1 && (o.n_chains % 64u) == 0 && (o.n_variants == 1 || cpv % 64u == 0) && !o.block_threads &&
         (uint64_t)n_vars * kParStateStride < 65536u && H < 16384) {
         bool ok = true;
@@ -698,7 +699,7 @@ void gr_sampler::rebuild() {
         d_plan.alloc((size_t)waves * plan_steps + 64);
     }
     if (sysscan) {
-        std::vector<uint32_t> order, pos, slots, recs;
+        std::vector<uint32_t> order, pos, slots, recs, rank_of_pos;
         for (uint32_t g = 0; g < n_build; ++g) {
             const VariantImage &im = image[g];
             order.insert(order.end(), im.sys_order.begin(), im.sys_order.end()); // (same pool layout as free_vars: free_base)
@@ -706,6 +707,7 @@ void gr_sampler::rebuild() {
             for (size_t i = 0; i < im.sys_order.size(); ++i) where[im.sys_order[i]] = (uint32_t)i;
             std::vector<uint32_t> rank((size_t)n_vars, 0);
             for (size_t i = 0; i < im.free_vars.size(); ++i) { pos.push_back(where[im.free_vars[i]]); rank[im.free_vars[i]] = (uint32_t)i; }
+            for (uint32_t v : im.sys_order) rank_of_pos.push_back(rank[v]); // free-list index of every position (k_scan_plan's systematic mode)
             if (!chroma) continue;
             h_variants[g].csl_base = (uint32_t)(slots.size() / 64u);
             for (size_t c = 0; c + 1 < im.color_off.size(); ++c)
@@ -724,6 +726,8 @@ void gr_sampler::rebuild() {
         order.resize(order.size() + 4, 0); pos.resize(pos.size() + 4, 0); slots.resize(slots.size() + 64, 0xffffffffu); recs.resize(recs.size() + 16, 0);
         d_sys_order.upload(order, stream, stage);
         d_sys_pos.upload(pos, stream, stage);
+        rank_of_pos.resize(rank_of_pos.size() + 4, 0);
+        d_sys_rank.upload(rank_of_pos, stream, stage);
         d_chroma_slots.upload(slots, stream, stage);
         d_recs_chroma.upload(recs, stream, stage);
         d_variants.upload(h_variants, stream, stage); // now with the lane slots
@@ -855,6 +859,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 a.chain_offset_lo = p.chain_offset_lo; a.chain_offset_hi = p.chain_offset_hi;
                 a.seed_lo = p.seed_lo; a.seed_hi = p.seed_hi; a.n_vars = (uint32_t)n_vars;
                 a.step0_lo = p.step0_lo; a.step0_hi = p.step0_hi;
+                a.sys_order = p.sys_order; // (systematic scan: set by the caller)
                 const uint32_t n_quads = (uint32_t)(((step + n - 1) >> 2) - (step >> 2) + 1);
                 p.scan_vars = d_scan_vars.p; p.scan_pitch = pw4_plan_steps / 4u + 2u;
                 hip_check(launch_scan_vars(a, n_quads, p.scan_pitch, d_scan_vars.p, stream), "k_scan_vars launch");
@@ -880,50 +885,27 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         T = 256; blocks = (act + 255) / 256;
         generic(n_total);
     };
-    if (cur_log_pc && !strict_fast) {
-        generic_small(updates); // strict mode's logged windows on the direct path: the generic kernel's per-chain scan with the per-chain log
-    } else if (sysscan) {
-        // systematic scan: whole sweeps from a sweep boundary on the chromatic kernel, everything else (and every model that
-        // kernel does not take) on the generic kernel's systematic mode -- same order, same draws, same thresholds
-        auto sys_generic = [&](uint64_t n_total) {
-            struct Restore { uint32_t &t, &b, kt, kb; ~Restore() { t = kt; b = kb; } } restore{T, blocks, T, blocks};
-            if (T > 256) { T = 256; blocks = (act + 255) / 256; }
-            uint64_t left = n_total;
-            while (left) {
-                const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
-                p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
-                p.n_steps = n;
-                p.sys_order = d_sys_order.p;
-                hip_check(launch_sweep(p, max_card, false, false, false, false, false, (act + T - 1) / T, T, lds, stream), "k_sweep (systematic) launch");
-                step += n; left -= n; launches_last++;
-            }
-        };
-        uint64_t left = updates;
-        if (chroma) {
-            FastParams f{};
-            f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p; f.cpt = d_cpt.p;
-            f.state = d_state.p; f.counts = d_counts.p;
-            f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = act; f.pitch = pitch; f.chains_per_variant = cpv;
-            f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
-            f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi; f.counting = p.counting;
-            f.chroma_slots = d_chroma_slots.p; f.recs_chroma = d_recs_chroma.p; f.sys_pos = d_sys_pos.p;
-            f.chroma_row = chroma_row; f.chroma_tab_off = chroma_tab_off; f.chroma_wpb = chroma_wpb; f.chroma_hist_off = chroma_hist_off; f.chroma_rec_off = chroma_rec_off;
-            const uint64_t head = std::min<uint64_t>(left, (sys_n_free - step % sys_n_free) % sys_n_free);
-            if (head) { sys_generic(head); left -= head; }
-            while (left >= sys_n_free) {
-                const uint64_t max_sweeps = std::max<uint64_t>(1, kMaxStepsPerLaunch / sys_n_free);
-                const uint32_t n = (uint32_t)(std::min<uint64_t>(left / sys_n_free, max_sweeps) * sys_n_free);
-                f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
-                f.n_steps = n;
-                hip_check(launch_sweep_chroma(f, (int)chroma_nslot, fast_slots, act / chroma_wpb, chroma_lds, stream), "k_sweep_chroma launch");
-                step += n; left -= n; launches_last++;
-            }
+    auto sys_generic = [&](uint64_t n_total) {
+        struct Restore { uint32_t &t, &b, kt, kb; ~Restore() { t = kt; b = kb; } } restore{T, blocks, T, blocks};
+        if (T > 256) { T = 256; blocks = (act + 255) / 256; }
+        uint64_t left = n_total;
+        while (left) {
+            const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
+            p.step0_lo = (uint32_t)step; p.step0_hi = (uint32_t)(step >> 32);
+            p.n_steps = n;
+            p.sys_order = d_sys_order.p;
+            hip_check(launch_sweep(p, max_card, false, false, false, false, false, (act + T - 1) / T, T, lds, stream), "k_sweep (systematic) launch");
+            step += n; left -= n; launches_last++;
         }
-        if (left) sys_generic(left);
-    } else if (dir4 && !fast) {
+    };
+    // k_scan_plan + k_sweep_dir4; sys: the systematic scan (the plan follows the sweep order, draws keyed by the position)
+    auto run_dir4 = [&](const uint64_t n_updates, const bool sys) {
+        auto ends = [&](uint64_t n) { if (sys) sys_generic(n); else generic_small(n); };
+        const uint64_t updates = n_updates;
         // quad-unaligned head and tail go through the generic kernel (bit-identical streams), the rest in launches of
         // k_scan_plan + k_sweep_dir4 (16 steps per inner iteration)
         FastParams f{};
+        f.sys_rank = sys ? d_sys_rank.p : nullptr;
         f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p;
         f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p; f.plan_pitch = plan_steps;
         f.rec_stride = 32; f.recs_par = d_dhdr.p; f.dent = d_dent.p; f.views = d_views.p; f.dir_view_off = dir_view_off; f.dir_ent_off = dir_ent_off;
@@ -941,7 +923,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.counting = p.counting; f.par_hist_off = dir_hist_off; f.par_stride = kParStateStride;
         uint64_t left = updates;
         const uint64_t head = std::min<uint64_t>(left, (16 - (step % 16)) % 16);
-        if (head) { generic_small(head); left -= head; }
+        if (head) { ends(head); left -= head; }
         while (left >= 16) {
             const uint32_t n = (uint32_t)std::min<uint64_t>(left - left % 16, plan_steps);
             f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
@@ -951,12 +933,15 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             hip_check(launch_sweep_dir4(f, max_card, dir4_vlds, dir4_elds, dir4_chain, act / 64u, dir_lds, stream), "k_sweep_dir4 launch");
             step += n; left -= n; launches_last++;
         }
-        if (left) generic_small(left);
-    } else if (!fast) {
-        generic(updates);
-    } else {
+        if (left) ends(left);
+    };
+    // the memoised fast kernels (k_sweep_bin / k_sweep_par4 / k_sweep_wide / k_sweep_strict); sys: the systematic scan on the wide form
+    auto run_fast = [&](const uint64_t n_updates, const bool sys) {
+        auto ends = [&](uint64_t n) { if (sys) sys_generic(n); else generic_small(n); };
+        const uint64_t updates = n_updates;
         // quad-unaligned head and tail go through the generic kernel (bit-identical streams)
         FastParams f{};
+        f.sys_rank = sys ? d_sys_rank.p : nullptr;
         f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p;
         f.cpt = d_cpt.p; f.recs = d_recs.p; f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p;
         f.plan_pitch = plan_steps;
@@ -998,12 +983,14 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             else if (o.fast_form == 9) lpc = 16;
             else if (o.fast_form == 0 && groups * 16u <= 4096u && (fit >= 4u || groups * 16u <= 256u * fit)) lpc = 16;
             else if (o.fast_form == 0 && groups * 8u <= 4096u) lpc = 8;
+            if (sys && lpc == 4) lpc = 8; // (the systematic scan exists in the wide forms only: k_sweep_par4 is left as it is)
         }
+        if (sys && lpc == 4) throw Error(GR_E_STATE, "systematic scan on the 4-lane form (internal error)");
         if (par) lpc_last = lpc;
         const uint64_t gran = strict_fast ? 4 : par ? 4u * lpc : 4; // steps per inner iteration of the fast kernels
         uint64_t left = updates;
         const uint64_t head = std::min<uint64_t>(left, (gran - (step % gran)) % gran);
-        if (head) { generic_small(head); left -= head; }
+        if (head) { ends(head); left -= head; }
         while (left >= gran) {
             const uint32_t n = (uint32_t)std::min<uint64_t>(left - left % gran, plan_steps);
             f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
@@ -1046,7 +1033,44 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             left -= n;
             launches_last++;
         }
-        if (left) generic_small(left);
+        if (left) ends(left);
+    };
+    if (cur_log_pc && !strict_fast) {
+        generic_small(updates); // strict mode's logged windows on the direct path: the generic kernel's per-chain scan with the per-chain log
+    } else if (sysscan) {
+        // systematic scan: whole sweeps from a sweep boundary on the chromatic kernel, everything else (and every model that
+        // kernel does not take) on the generic kernel's systematic mode -- same order, same draws, same thresholds
+        uint64_t left = updates;
+        if (chroma) {
+            FastParams f{};
+            f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p; f.cpt = d_cpt.p;
+            f.state = d_state.p; f.counts = d_counts.p;
+            f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = act; f.pitch = pitch; f.chains_per_variant = cpv;
+            f.chain_offset_lo = p.chain_offset_lo; f.chain_offset_hi = p.chain_offset_hi;
+            f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi; f.counting = p.counting;
+            f.chroma_slots = d_chroma_slots.p; f.recs_chroma = d_recs_chroma.p; f.sys_pos = d_sys_pos.p;
+            f.chroma_row = chroma_row; f.chroma_tab_off = chroma_tab_off; f.chroma_wpb = chroma_wpb; f.chroma_hist_off = chroma_hist_off; f.chroma_rec_off = chroma_rec_off;
+            const uint64_t head = std::min<uint64_t>(left, (sys_n_free - step % sys_n_free) % sys_n_free);
+            if (head) { sys_generic(head); left -= head; }
+            while (left >= sys_n_free) {
+                const uint64_t max_sweeps = std::max<uint64_t>(1, kMaxStepsPerLaunch / sys_n_free);
+                const uint32_t n = (uint32_t)(std::min<uint64_t>(left / sys_n_free, max_sweeps) * sys_n_free);
+                f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
+                f.n_steps = n;
+                hip_check(launch_sweep_chroma(f, (int)chroma_nslot, fast_slots, act / chroma_wpb, chroma_lds, stream), "k_sweep_chroma launch");
+                step += n; left -= n; launches_last++;
+            }
+        }
+        else if (pw4) { p.sys_order = d_sys_order.p; generic(left); left = 0; } // k_scan_vars + k_sweep_pw4<SYS>
+        else if (dir4 && !fast) { run_dir4(left, true); left = 0; }
+        else if (sys_wide()) { run_fast(left, true); left = 0; } // memoised binary models the chromatic kernel does not take: k_sweep_wide
+        if (left) sys_generic(left);
+    } else if (dir4 && !fast) {
+        run_dir4(updates, false);
+    } else if (!fast) {
+        generic(updates);
+    } else {
+        run_fast(updates, false);
     }
     hip_check(hipEventRecord(ev1, stream), "hipEventRecord");
     uint32_t dev_err = 0;
@@ -2146,7 +2170,7 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         out->block_threads = s->T; out->n_blocks = s->blocks;
         out->lds_bytes = s->sysscan && s->chroma ? s->chroma_lds : s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->dir4 ? s->dir_lds : s->lds; // of the kernel that actually runs
         if (s->fast && s->par) { out->block_threads = s->strict_fast ? s->T : 64u * s->lpc_last; out->n_blocks = s->active_chains() / 64u; } // (64 x lanes per chain of the last launch)
-        out->path = s->sysscan ? (s->chroma ? 9u : 0u) : s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
+        out->path = s->sysscan ? (s->chroma ? 9u : s->pw4 ? 6u : (s->dir4 && !s->fast) ? 8u : s->sys_wide() ? 3u : 0u) : s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

@@ -63,9 +63,14 @@ __global__ void __launch_bounds__(256) k_scan_plan(const FastParams p) {
     const u32x4 sc = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)(gchain0 >> 6), DOM_SCAN, p.seed_lo, p.seed_hi);
     const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w};
     uint32_t k[4], v[4], out[4], level[4], maxlv = 0;
+    uint32_t sys_p = p.sys_rank ? (uint32_t)((q << 2) % vd.n_free) : 0u; // systematic scan: step t updates position t mod n of the order
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         k[j] = mul_hi_u32(su[j], vd.n_free);
+        if (p.sys_rank) {
+            k[j] = p.sys_rank[vd.free_base + sys_p];
+            if (++sys_p == vd.n_free) sys_p = 0;
+        }
         const unsigned short *e = sp_tab + k[j] * S;
         v[j] = e[0];
         // dependency level of step j inside its quad: 1 + the highest level of an earlier step that
@@ -971,6 +976,14 @@ __global__ void __launch_bounds__(256) k_scan_plan_wide(const FastParams p) {
         k[4 * c] = mul_hi_u32(sc.x, vd.n_free); k[4 * c + 1] = mul_hi_u32(sc.y, vd.n_free);
         k[4 * c + 2] = mul_hi_u32(sc.z, vd.n_free); k[4 * c + 3] = mul_hi_u32(sc.w, vd.n_free);
     }
+    if (p.sys_rank) { // systematic scan: step t updates position t mod n of the sweep order
+        uint32_t sys_p = (uint32_t)((q0 << 2) % vd.n_free);
+#pragma unroll
+        for (int j = 0; j < LPC; ++j) {
+            k[j] = p.sys_rank[vd.free_base + sys_p];
+            if (++sys_p == vd.n_free) sys_p = 0;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < LPC; ++j) {
         const unsigned short *e = sp_tab + k[j] * S;
@@ -1081,12 +1094,31 @@ __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const Fa
     prefetch_plan(0); prefetch(rA, pwA); prefetch_plan(4);
     if constexpr (ROUND_AHEAD) fetch(rA[0], pwA[0]); // round 0's record; from here on set A serves the even rounds, set B the odd ones
 
+    // GR_FLAG_SCAN_SYSTEMATIC (p.sys_rank set): the plan follows the sweep order and update t of a chain takes word (sweep & 3) of
+    // philox_sys_draw(sweep = t / n, pos = t mod n, chain) -- one Philox call per step.  My steps are LPC apart.
+    const bool sys = !DENSE && p.sys_rank != nullptr;
+    uint64_t sys_sweep = 0;
+    uint32_t sys_pos = 0;
+    if (sys) {
+        const uint64_t s_first = (q0 << 2) + j;
+        sys_sweep = s_first / vd.n_free;
+        sys_pos = (uint32_t)(s_first - sys_sweep * vd.n_free);
+    }
     auto iteration = [&](const uint32_t it, RecL<SLOTS, PACKED> (&rc)[NSET], uint32_t (&pwc)[4], RecL<SLOTS, PACKED> (&rx)[NSET], uint32_t (&pwx)[4]) {
-        // draws: my Philox call is quad it * LPC + slot; two lane-swap pairs leave U[k] = my word of round k (see the header)
-        const uint64_t q = q0 + (uint64_t)it * LPC + slot;
-        const u32x4 Wd = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
         uint32_t U[4];
-        {
+        if (sys) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 d = philox_sys_draw(sys_sweep, sys_pos, gchain, p.seed_lo, p.seed_hi);
+                const uint32_t w = (uint32_t)sys_sweep & 3u;
+                U[k] = w == 0 ? d.x : w == 1 ? d.y : w == 2 ? d.z : d.w;
+                sys_pos += (uint32_t)LPC;
+                while (sys_pos >= vd.n_free) { sys_pos -= vd.n_free; ++sys_sweep; }
+            }
+        } else {
+            // draws: my Philox call is quad it * LPC + slot; two lane-swap pairs leave U[k] = my word of round k (see the header)
+            const uint64_t q = q0 + (uint64_t)it * LPC + slot;
+            const u32x4 Wd = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
             const auto a = __builtin_amdgcn_permlane32_swap(Wd.x, Wd.z, false, false);
             const auto b = __builtin_amdgcn_permlane32_swap(Wd.y, Wd.w, false, false);
             const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);

@@ -183,13 +183,33 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
         return pick<MAXC>(cum, tot, C, u);
     };
 
+    // GR_FLAG_SCAN_SYSTEMATIC (p.sys_rank set; never with the draw log): the plan follows the sweep order and update t of a chain
+    // takes word (sweep & 3) of philox_sys_draw(sweep = t / n, pos = t mod n, chain) -- one Philox call per step.  My steps are
+    // 4 apart: position and sweep number are kept by increments.
+    const bool sys = !LOG && p.sys_rank != nullptr;
+    uint64_t sys_sweep = 0;
+    uint32_t sys_pos = 0;
+    if (sys) {
+        const uint64_t s_first = (q0 << 2) + j;
+        sys_sweep = s_first / vd.n_free;
+        sys_pos = (uint32_t)(s_first - sys_sweep * vd.n_free);
+    }
     for (uint32_t g0 = 0; g0 < nq; g0 += 4) {
-        // draws: my Philox call is quad g0 + j; a 4x4 transpose (step slots x words) with gfx950's lane swaps leaves lane
-        // (j, c) with word j of quads g0 .. g0 + 3 (see k_sweep_par4)
-        const uint64_t q = q0 + g0 + j;
-        const u32x4 W = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
         uint32_t U[4];
-        {
+        if (sys) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 d = philox_sys_draw(sys_sweep, sys_pos, gchain, p.seed_lo, p.seed_hi);
+                const uint32_t w = (uint32_t)sys_sweep & 3u;
+                U[k] = w == 0 ? d.x : w == 1 ? d.y : w == 2 ? d.z : d.w;
+                sys_pos += 4u;
+                while (sys_pos >= vd.n_free) { sys_pos -= vd.n_free; ++sys_sweep; }
+            }
+        } else {
+            // draws: my Philox call is quad g0 + j; a 4x4 transpose (step slots x words) with gfx950's lane swaps leaves lane
+            // (j, c) with word j of quads g0 .. g0 + 3 (see k_sweep_par4)
+            const uint64_t q = q0 + g0 + j;
+            const u32x4 W = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
             const auto a = __builtin_amdgcn_permlane32_swap(W.x, W.z, false, false);
             const auto b = __builtin_amdgcn_permlane32_swap(W.y, W.w, false, false);
             const auto c = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);

@@ -159,7 +159,11 @@ __device__ __forceinline__ void pw4_cond(float (&w)[NP][4], const int (&C)[NP], 
 
 // LOG: write the draw log of gr_advance_chain (one row per wavefront = 16 chains, one count per value and step) and stop at
 // the group's own stopping time (SweepParams::log / limit).
-template <bool LOG>
+// SYS: GR_FLAG_SCAN_SYSTEMATIC -- the launch's variables (k_scan_vars) follow the sweep order, and update t of a chain takes
+// word (sweep & 3) of philox_sys_draw(sweep = t / n, pos = t mod n, chain): one Philox call per step instead of one per quad
+// (the stream is keyed by the position so that k_sweep_chroma's lanes, which own positions, need one call per 4 sweeps).
+// Consecutive positions of a colour class never share a factor, so nearly every step runs paired with the next one.
+template <bool LOG, bool SYS = false>
 __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -264,11 +268,28 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
         if (lane < 16u && lane < p.log_vals && logrow) logrow[(size_t)sidx * p.log_vals + lane] = (unsigned char)__popcll(m);
     };
 
+    // SYS: sweep number and position in the order of the current quad's first step (uniform), kept by increments
+    uint64_t sys_sweep = 0;
+    uint32_t sys_pos = 0;
+    if constexpr (SYS) {
+        const uint64_t s_first = (step0 >> 2) << 2;
+        sys_sweep = s_first / vd.n_free;
+        sys_pos = (uint32_t)(s_first - sys_sweep * vd.n_free);
+    }
+    auto sys_draw = [&](const uint32_t j) -> uint32_t { // the draw of step j of the current quad
+        uint64_t sw = sys_sweep;
+        uint32_t ps = sys_pos + j;
+        while (ps >= vd.n_free) { ps -= vd.n_free; ++sw; }
+        const u32x4 d = philox_sys_draw(sw, ps, gchain, p.seed_lo, p.seed_hi);
+        const uint32_t w = (uint32_t)sw & 3u;
+        return w == 0 ? d.x : w == 1 ? d.y : w == 2 ? d.z : d.w;
+    };
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
         const u32x2v sv = plan[q - (step0 >> 2)]; // the quad's four variables, 16 bits each
         const uint32_t sc[4] = {sv[0] & 0xffffu, sv[0] >> 16, sv[1] & 0xffffu, sv[1] >> 16};
-        const u32x4 dr = philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
+        u32x4 dr{0, 0, 0, 0};
+        if constexpr (!SYS) dr = philox4x32_10(q_lo, q_hi, (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
         // step index inside the launch, as 32 bits: a step before step0 (first quad of a quad-unaligned launch) wraps to a huge
         // value, so ONE unsigned scalar compare against the launch length covers both ends (64-bit compares are VALU work)
         const uint32_t rel0 = (uint32_t)((q << 2) - step0);
@@ -279,7 +300,7 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
             if (sidx >= p.n_steps) { ++j; continue; }
             if (LOG && sidx >= lim) { ++j; continue; } // the group has finished its AdvanceChain: nothing changes any more
             const StepHdr ha = header(j == 0 ? sc[0] : j == 1 ? sc[1] : j == 2 ? sc[2] : sc[3]); // (no register arrays indexed by j)
-            const uint32_t dua = j == 0 ? dr.x : j == 1 ? dr.y : j == 2 ? dr.z : dr.w;
+            const uint32_t dua = SYS ? sys_draw((uint32_t)j) : j == 0 ? dr.x : j == 1 ? dr.y : j == 2 ? dr.z : dr.w;
             // the next step runs together with this one when it exists and its variable is neither this one nor a neighbour
             bool pair = j < 3 && sidx + 1u < p.n_steps && (!LOG || sidx + 1u < lim);
             StepHdr hb = ha;
@@ -289,7 +310,7 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
                 pair = (((bit < 32u ? ha.f_lo >> bit : ha.f_hi >> (bit - 32u)) & 1u) == 0u);
             }
             if (pair) {
-                const uint32_t dub = j == 0 ? dr.y : j == 1 ? dr.z : dr.w;
+                const uint32_t dub = SYS ? sys_draw((uint32_t)j + 1u) : j == 0 ? dr.y : j == 1 ? dr.z : dr.w;
                 float w[2][4];
                 gather(ha, w[0]);
                 gather(hb, w[1]);
@@ -315,6 +336,10 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
                 j += 1;
             }
         }
+        if constexpr (SYS) {
+            sys_pos += 4u;
+            while (sys_pos >= vd.n_free) { sys_pos -= vd.n_free; ++sys_sweep; }
+        }
     }
 
     __syncthreads();
@@ -335,6 +360,7 @@ hipError_t launch_sweep_pw4(const SweepParams &p, uint32_t blocks, uint32_t lds_
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds_bytes, s, p);
         return hipGetLastError();
     };
+    if (p.sys_order) return (p.log || p.limit) ? hipErrorInvalidValue : go(&k_sweep_pw4<false, true>);
     return (p.log || p.limit) ? go(&k_sweep_pw4<true>) : go(&k_sweep_pw4<false>);
 }
 

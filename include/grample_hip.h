@@ -122,6 +122,8 @@ int gr_error_suite(int32_t n_vars, const int32_t *card, const int32_t *fixed1, c
                                             model's, like the random scan's; the chain's law is NOT the reference's (off by default).
                                             Binary memoisable models (up to 8 lane slots of 64 variables per colour chunk, 12 neighbours) run k_sweep_chroma / k_sweep_chroma_l: one wavefront per chain, one lane per
                                             variable of a colour class, all of a class updated side by side -- full occupancy from 4 096 chains up.
+                                            The other model families keep their random-scan kernels (paths 6, 8 and the 8 / 16-lane form of path 3) with
+                                            the plan following the sweep order; the generic kernel (path 0) serves what is left.
                                             Not combinable with GR_FLAG_SCAN_PER_CHAIN; gr_advance_chain / gr_advance_window keep working through
                                             gr_advance_window only (the stopping rule of AdvanceChain is a property of the random scan). */
 

@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import grample_amd as g
 RES = os.path.join(ROOT, "tests", "golden", "res")
-for name, nch in [("Grids_11.uai", 4096), ("Grids_13.uai", 4096), ("Grids_13.uai", 16384), ("Grids_13.uai", 65536), ("Grids_13.uai", 262144), ("Segmentation_11.uai", 32768), ("ObjectDetection_13.uai", 32768)]:
+for name, nch in [("Grids_11.uai", 4096), ("Grids_13.uai", 4096), ("Grids_13.uai", 16384), ("Grids_13.uai", 65536), ("Grids_13.uai", 262144), ("Segmentation_11.uai", 32768), ("ObjectDetection_13.uai", 32768),
+                  ("CSP_13.uai", 32768), ("Alchemy_11.uai", 32768), ("Pedigree_11.uai", 32768), ("Promedus_14.uai", 32768)][int(os.environ.get("DEV_SYS_FROM", "0")):]:
     m = g.Model.NewModelFromFile(os.path.join(RES, name))
     n = m.n_vars
     row = []

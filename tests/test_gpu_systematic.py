@@ -29,12 +29,16 @@ def _gm(pm):
 @pytest.mark.parametrize("name,ev,chains,burn,steps,flags,path", [
     ("Grids_11.uai", False, 128, 13, 457, 0, 9),            # chromatic kernel; the launches start and end inside a sweep
     ("Grids_11.uai", False, 64, 250, 230, g.GR_FLAG_DIRECT, 0),  # generic kernel, systematic mode
-    ("ObjectDetection_13.uai", False, 64, 7, 150, 0, 0),    # Card 16
+    ("ObjectDetection_13.uai", False, 64, 7, 150, 0, 6),    # Card 16: k_scan_vars + k_sweep_pw4 on the sweep order, one Philox call per step
+    ("ObjectDetection_13.uai", False, 64, 7, 150, g.GR_FLAG_CHAIN_PER_LANE, 0),  # ... and the generic kernel
     ("Pedigree_11.uai", True, 64, 5, 700, 0, 9),            # with its evidence every selectable variable is binary: records in LDS
-    ("Pedigree_11.uai", False, 64, 5, 300, 0, 0),           # Card 3, arity 4: generic kernel
+    ("Pedigree_11.uai", False, 64, 5, 300, 0, 8),           # Card 3, arity 4: k_scan_plan + k_sweep_dir4 on the sweep order
+    ("Pedigree_11.uai", False, 64, 5, 300, g.GR_FLAG_CHAIN_PER_LANE, 0),  # ... and the generic kernel
+    ("CSP_12.uai", False, 64, 3, 180, 0, 8),                # Card 4, dense
     ("grid3x3", False, 192, 3, 100, 0, 9),
     ("Segmentation_11.uai", False, 64, 9, 500, 0, 9),      # 228 variables, more lane slots than registers hold: records staged in LDS (k_sweep_chroma_l)
-    ("Promedus_11.uai", True, 64, 5, 900, 0, 0),           # evidence, arity 3: more than 8 lane slots -> generic kernel
+    ("Promedus_11.uai", True, 64, 5, 900, 0, 3),           # evidence, arity 3: more than 8 lane slots -> k_scan_plan_wide + k_sweep_wide on the sweep order
+    ("Promedus_11.uai", True, 64, 5, 900, g.GR_FLAG_DIRECT, 0),  # ... and the generic kernel
     ("mixed_evidence", False, 64, 2, 41, 0, 0),
 ])
 def test_systematic_sweep_bitwise_vs_emulator(res_dir, name, ev, chains, burn, steps, flags, path):
@@ -131,6 +135,27 @@ def test_systematic_marginals_match_oracle_random_scan(oracle, res_dir, name, bu
     eo = g.NewErrorSuite(pm.card, sol, split(po.mean(axis=0) + 1e-12))
     eg = g.NewErrorSuite(pm.card, sol, split(pg.mean(axis=0) + 1e-12))
     assert abs(eo["MeanHellinger"] - eg["MeanHellinger"]) <= 0.02, (eo, eg)
+
+
+@pytest.mark.parametrize("name,ev,chains,path", [("ObjectDetection_13.uai", False, 2048, 6), ("ObjectDetection_11.uai", False, 1024, 6), ("CSP_13.uai", False, 2048, 8),
+                                                  ("Alchemy_11.uai", False, 1024, 8), ("Pedigree_11.uai", False, 1024, 8),
+                                                  ("Promedus_14.uai", False, 1024, 3), ("Promedus_14.uai", False, 40960, 3), ("Promedus_11.uai", True, 2048, 3),
+                                                  ("Promedus_17.uai", True, 512, 3)])
+def test_plan_based_kernels_equal_generic_systematic(res_dir, name, ev, chains, path):
+    """The systematic scan on the plan-based kernels (k_sweep_pw4: path 6, k_sweep_dir4: path 8, k_sweep_wide with 8 or 16 lanes
+    per chain: path 3 -- the plan follows the sweep order, draws are keyed by (sweep, position)) is the generic kernel's
+    systematic mode bit for bit: launches that start and end inside a quad and inside a sweep, 64-bit chain ids, several sweeps."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name), ev)
+    n = m.n_vars
+    out = []
+    for flags in (SYS, SYS | (g.GR_FLAG_DIRECT if path == 3 else g.GR_FLAG_CHAIN_PER_LANE)):
+        s = g.HIPChains(m, chains, seed=9, chain_offset=(1 << 35) + 64 * 3, flags=flags)
+        s.BurnIn(45); s.Advance(3 * n + 7); s.Advance(66); s.Advance(2 * n)
+        out.append((s.info()["path"], s.counts(), s.checkpoint()["states"]))
+        s.close()
+    assert out[0][0] == path and out[1][0] == 0
+    assert np.array_equal(out[0][1], out[1][1]) and np.array_equal(out[0][2], out[1][2])
+    assert int(out[0][1].sum()) == chains * (5 * n + 73)
 
 
 def test_systematic_flag_rules(res_dir):
