@@ -158,6 +158,35 @@ def test_plan_based_kernels_equal_generic_systematic(res_dir, name, ev, chains, 
     assert int(out[0][1].sum()) == chains * (5 * n + 73)
 
 
+@pytest.mark.parametrize("name,path", [("CSP_13.uai", 8), ("Alchemy_11.uai", 8), ("Promedus_14.uai", 3), ("Segmentation_11.uai", 3)])
+def test_systematic_plan_kernels_with_collapsed_groups(res_dir, name, path):
+    """Systematic scan + collapsed chain groups (each group its own order: the collapsed variable leaves it, the COLLAPSE factor
+    re-colours its neighbours; groups of different sweep lengths in one launch): k_sweep_dir4 with chained entries and
+    k_sweep_wide equal the generic kernel bit for bit -- counts, states, the two halves of gr_advance_window, resume from a
+    checkpoint taken inside a sweep."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    out = []
+    for flags in (SYS, SYS | g.GR_FLAG_DIRECT | g.GR_FLAG_CHAIN_PER_LANE):
+        s = g.HIPChains(m, 768, n_variants=3, seed=4, flags=flags)
+        cv = [s.Collapse(k, -1)[0] for k in (1, 2)]
+        s.BurnIn(29); s.Advance(2 * m.n_vars + 5)
+        path_seen = s.info()["path"]
+        ck = s.checkpoint()
+        s.AdvanceWindow(150)
+        a, b, cw = s.window_halves()
+        t = g.HIPChains(m, 768, n_variants=3, seed=4, flags=flags)
+        for k, v in zip((1, 2), cv):
+            t.Collapse(k, v)
+        t.restore(ck); t.AdvanceWindow(150)
+        assert np.array_equal(t.counts(), s.counts())
+        out.append((path_seen, cv, s.counts(), s.checkpoint()["states"], a, b))
+        s.close(); t.close()
+    assert out[0][0] == path and out[1][0] == 0 and out[0][1] == out[1][1]
+    for i in (2, 3, 4, 5):
+        assert np.array_equal(out[0][i], out[1][i])
+    assert out[0][4].sum() + out[0][5].sum() == 768 * 150  # every update of the window lands in one half
+
+
 def test_systematic_flag_rules(res_dir):
     m = g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai"))
     with pytest.raises(g.GrError):
