@@ -26,6 +26,10 @@ def model(rng, kind):
         n = int(rng.integers(40, 200))
         card = [2] * n
         arity = 4
+    elif kind == "dense_small":         # k_sweep_dir4 territory: Card 2..4, blankets too large to memoise
+        n = int(rng.integers(20, 90))
+        card = [int(rng.choice([2, 3, 4, 4])) for _ in range(n)]
+        arity = int(rng.choice([2, 3]))
     else:                               # small mixed cards, arity up to 4: generic kernels
         n = int(rng.integers(5, 60))
         card = [int(rng.choice([2, 2, 3, 4, 5])) for _ in range(n)]
@@ -33,7 +37,7 @@ def model(rng, kind):
     scopes, tables = [], []
     for v in range(n):
         scopes.append([v]); tables.append(np.exp(rng.uniform(-2, 2, card[v])))
-    nf = int(n * rng.uniform(0.8, 2.5 if kind != "binary_medium" else 1.2))
+    nf = int(n * (rng.uniform(3.0, 6.0) if kind == "dense_small" else rng.uniform(0.8, 2.5 if kind != "binary_medium" else 1.2)))
     for _ in range(nf):
         k = int(rng.integers(2, arity + 1))
         sc = [int(x) for x in rng.choice(n, min(k, n), replace=False)]
@@ -48,8 +52,10 @@ def model(rng, kind):
     return SimpleNamespace(card=card, scopes=scopes, tables=tables, fixed=fixed)
 
 
-def run(m, chains, seed, off, **kw):
+def run(m, chains, seed, off, collapse=None, **kw):
     s = g.HIPChains(m, chains, seed=seed, chain_offset=off, **kw)
+    if collapse is not None:  # the last group collapses this variable (-1: the sampler's own pick; the caller passes the pick on to the other forms)
+        collapse.append(s.Collapse(kw["n_variants"] - 1, collapse.pop() if collapse else -1)[0])
     s.BurnIn(29); s.Advance(77); s.Advance(50)
     i = s.info()
     out = (i["path"] + (32 if i["tables_in_lds"] == 2 else 0), s.counts().copy(), s.checkpoint()["states"].copy())  # 35 = path 3, split pool
@@ -60,7 +66,7 @@ def run(m, chains, seed, off, **kw):
 def main():
     n_models = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    kinds = ["bigcard_pairwise", "binary_sparse", "binary_medium", "mixed"]
+    kinds = ["bigcard_pairwise", "binary_sparse", "binary_medium", "mixed", "dense_small"]
     seen = {}
     for i in range(n_models):
         kind = kinds[i % len(kinds)]
@@ -95,11 +101,24 @@ def main():
         # systematic scan: chromatic kernel (when the model qualifies) vs the generic kernel's systematic mode
         try:
             a = run(m, chains, seed, off, flags=g.GR_FLAG_SCAN_SYSTEMATIC)
-            b = run(m, chains, seed, off, flags=g.GR_FLAG_SCAN_SYSTEMATIC | g.GR_FLAG_DIRECT)
+            b = run(m, chains, seed, off, flags=g.GR_FLAG_SCAN_SYSTEMATIC | g.GR_FLAG_DIRECT | g.GR_FLAG_CHAIN_PER_LANE)
             assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (i, kind, "systematic")
             paths += [a[0] + 100, b[0] + 100]
         except g.GrError:
             pass
+        # two chain groups, the second with one variable collapsed (a factor over its whole blanket joins the model): the
+        # sampler's own choice of kernel (4-lane forms with chained entries / split pools) vs the generic kernel, random and systematic scan
+        if chains % 128 == 0:
+            for fl, tag in ((0, 200), (g.GR_FLAG_SCAN_SYSTEMATIC, 300)):
+                try:
+                    cv = []
+                    a = run(m, chains, seed, off, collapse=cv, n_variants=2, flags=fl)
+                    b = run(m, chains, seed, off, collapse=cv, n_variants=2, flags=fl | g.GR_FLAG_DIRECT | g.GR_FLAG_CHAIN_PER_LANE)
+                    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]), (i, kind, "collapsed", tag, cv)
+                    paths += [a[0] + tag, b[0] + tag]
+                except g.GrError as e:
+                    if "[-5]" not in str(e) and "[-3]" not in str(e) and "[-1]" not in str(e):
+                        raise
         for p in paths:
             seen[p] = seen.get(p, 0) + 1
         print(f"model {i:3d} {kind:18s} n={len(pm.card):3d} chains={chains:3d} default path {ref[0]:2d} forms {sorted(set(paths))} ok", flush=True)
