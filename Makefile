@@ -20,35 +20,35 @@ all: $(LIB) oracle $(TOOL)
 $(TOOL): tools/grample_hip_sample.cpp include/grample_hip.h $(LIB)
 	g++ -O2 -std=c++17 -Wall -o $@ $< -Lgrample_amd -lgrample_hip -Wl,-rpath,'$$ORIGIN/../grample_amd' -Wl,-rpath,/opt/rocm/lib
 
-$(OBJDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/cond.h
+$(OBJDIR)/kernels.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/wave_prio.h $(CSRC)/cond.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 # the instantiations of the generic k_sweep for Card <= 16 and Card <= 64 (kernels.hip, GR_KSWEEP_PART)
-$(OBJDIR)/kernels_%.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/cond.h
+$(OBJDIR)/kernels_%.o: $(CSRC)/kernels.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/wave_prio.h $(CSRC)/cond.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DGR_KSWEEP_PART=$* -c $< -o $@
 
-$(OBJDIR)/sweep_bin.o: $(CSRC)/sweep_bin.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h
+$(OBJDIR)/sweep_bin.o: $(CSRC)/sweep_bin.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/wave_prio.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 # the instantiations of k_sweep_par4, by record shape (sweep_bin.hip, GR_PAR4_PART): four translation units built side by side
-$(OBJDIR)/sweep_par4_%.o: $(CSRC)/sweep_bin.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h
+$(OBJDIR)/sweep_par4_%.o: $(CSRC)/sweep_bin.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/wave_prio.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DGR_PAR4_PART=$* -c $< -o $@
 
-$(OBJDIR)/sweep_chroma.o: $(CSRC)/sweep_chroma.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h
+$(OBJDIR)/sweep_chroma.o: $(CSRC)/sweep_chroma.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/wave_prio.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(OBJDIR)/sweep_dir4.o: $(CSRC)/sweep_dir4.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/cond.h
+$(OBJDIR)/sweep_dir4.o: $(CSRC)/sweep_dir4.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/wave_prio.h $(CSRC)/cond.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 # max-ilp: the value-parallel kernel runs two independent conditionals per wavefront (pw4_cond<2>); the default scheduler
 # emits them one after the other, this one interleaves their dependent f64 chains
-$(OBJDIR)/sweep_pw4.o: $(CSRC)/sweep_pw4.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/cond.h
+$(OBJDIR)/sweep_pw4.o: $(CSRC)/sweep_pw4.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/wave_prio.h $(CSRC)/cond.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -mllvm -amdgpu-sched-strategy=max-ilp -c $< -o $@
 

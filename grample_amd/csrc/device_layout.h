@@ -105,6 +105,7 @@ struct FastParams {
     const uint32_t *recs_par;
     uint32_t par_hist_off, par_tab_off, par_rec_off, par_plan_off, par_scr_off;
     uint32_t *err;               // device error word (bit 0: the dynamic LDS array does not start at LDS address 0)
+    unsigned long long *dbg_times; // measurements only (GR_DEV_BLOCK_TIMES): per block of k_sweep_par4 {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}, or null
     uint32_t par_recmode;        // k_sweep_par4 record source: 0 LDS per step, 1 LDS fetched together, 2 global prefetched, other = auto
     uint32_t plan_slots, plan_nfree_max; // k_scan_plan's LDS table: most neighbours of a variable, most selectable variables of a group
     uint32_t strict_state_off;   // k_sweep_strict with 4 waves per block: state regions of waves 1..3

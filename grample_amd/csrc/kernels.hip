@@ -26,6 +26,7 @@
 #include "device_layout.h"
 #include "kernels.h"
 #include "philox.h"
+#include "wave_prio.h"
 #include "cond.h"
 
 // Compiled three times (Makefile): GR_KSWEEP_PART 0 = everything, with the instantiations of k_sweep for Card <= 4 only;
@@ -302,8 +303,10 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
         sys_sweep = s_first / vd.n_free;
         sys_pos = (uint32_t)(s_first - sys_sweep * vd.n_free);
     }
+    const PrioRotor prio; // (wave_prio.h: the blocks of a CU progress as equals)
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
+        prio.tick<5>(q_lo);
         uint32_t su[4] = {0, 0, 0, 0}, du[4];
         uint32_t v[4];
         cu32p pg[4];

@@ -167,6 +167,7 @@ struct gr_sampler {
     bool chroma = false;              // ... on k_sweep_chroma (binary memoised, few lane slots); else the generic kernel's systematic mode
     uint32_t chroma_row = 0, chroma_tab_off = 0, chroma_hist_off = 0, chroma_rec_off = 0, chroma_lds = 0, chroma_nslot = 0, sys_n_free = 0, chroma_wpb = 4;
     DevBuf<uint32_t> d_sys_order, d_sys_pos, d_sys_rank, d_chroma_slots, d_recs_chroma;
+    DevBuf<unsigned long long> d_dbg; // GR_DEV_BLOCK_TIMES (measurements only)
     bool no_wide = false;             // fast_form 3: every automatic choice, but never the wide form (measurements)
     bool wide_ok = false;             // ... the 8 / 16 lanes-per-chain form (k_sweep_wide) may take its place when wavefronts are what a launch lacks
     uint32_t lpc_last = 4;            // lanes per chain of the last step-parallel launch (gr_sampler_get_info)
@@ -1027,7 +1028,20 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 continue;
             }
             hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
-            if (par) hip_check(launch_sweep_par4(f, fast_slots, par_packed, act / 64u, par_lds, stream), "k_sweep_par4 launch");
+            if (par) {
+                // (measurements only) GR_DEV_BLOCK_TIMES=<file>: start / end time (100 MHz), HW_ID and XCC_ID of every block of the last k_sweep_par4 launch
+                const char *bt = getenv("GR_DEV_BLOCK_TIMES");
+                if (bt) { d_dbg.alloc((size_t)(act / 64u) * 4u); f.dbg_times = d_dbg.p; }
+                hip_check(launch_sweep_par4(f, fast_slots, par_packed, act / 64u, par_lds, stream), "k_sweep_par4 launch");
+                if (bt) {
+                    std::vector<unsigned long long> t((size_t)(act / 64u) * 4u);
+                    download(t.data(), d_dbg.p, t.size() * 8u);
+                    if (FILE *fp = fopen(bt, "w")) {
+                        for (size_t b = 0; b < t.size() / 4u; ++b) fprintf(fp, "%zu %llu %llu %llu %llu\n", b, t[4 * b], t[4 * b + 1], t[4 * b + 2], t[4 * b + 3]);
+                        fclose(fp);
+                    }
+                }
+            }
             else hip_check(launch_sweep_bin(f, fast_slots, act / T, T, lds, stream), "k_sweep_bin launch");
             step += n;
             left -= n;

@@ -26,11 +26,15 @@
 #include "device_layout.h"
 #include "kernels.h"
 #include "philox.h"
+#include "wave_prio.h"
 
 // This file is compiled five times (Makefile): GR_PAR4_PART 0 = everything but the instantiations of k_sweep_par4, parts
 // 1..4 = those, by record shape -- 330 instantiations of that kernel in one translation unit took four minutes to build.
 #ifndef GR_PAR4_PART
 #define GR_PAR4_PART 0
+#endif
+#ifndef GR_PAR4_PRIO_SHIFT
+#define GR_PAR4_PRIO_SHIFT 5 // k_sweep_par4 rotates its wavefront priority every 2^5 quads (wave_prio.h; 3: 8.32e11, 5: 8.40e11, 7: 8.3e11 on the headline)
 #endif
 
 namespace gr {
@@ -262,7 +266,9 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
         }
     };
 
+    const PrioRotor prio; // (wave_prio.h)
     for (uint32_t qi = 0; qi < nq; ++qi) {
+        prio.tick<8>(qi);
         const uint64_t q = q0 + qi;
         if ((qi & (kPlanChunk - 1u)) == kPlanChunk / 2u) {
             // mid-chunk: park the prefetched next chunk in the other half of the ring, fetch the one after it
@@ -467,6 +473,7 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     const uint32_t chain = group * 64u + cb;
     const uint32_t variant = (group * 64u) / p.chains_per_variant;
     const VariantDesc vd = p.variants[variant];
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime(); // (for p.dbg_times)
     {   // stage tables + records, this block's 64 chains, zero the block histogram
         const uint32_t n4 = ((TABG == 2 ? min(vd.cpt_len, p.par_tab_words) : vd.cpt_len) + 3u) >> 2;
         const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
@@ -708,14 +715,18 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         iteration(std::false_type{}, g0, rc, pwc, rx, pwx);
         return true;
     };
+    const PrioRotor prio; // (wave_prio.h: the blocks of a CU progress as equals)
     if constexpr (RECMODE == 2) {
         for (uint32_t g0 = 0; g0 < nq; g0 += 8) {
+            prio.tick<GR_PAR4_PRIO_SHIFT>(g0);
             if (!run(g0, rA, pwA, rB, pwB)) break;
             if (g0 + 4u < nq && !run(g0 + 4u, rB, pwB, rA, pwA)) break;
         }
     } else {
-        for (uint32_t g0 = 0; g0 < nq; g0 += 4)
+        for (uint32_t g0 = 0; g0 < nq; g0 += 4) {
+            prio.tick<GR_PAR4_PRIO_SHIFT>(g0);
             if (!run(g0, rA, pwA, rB, pwB)) break;
+        }
     }
 
     for (uint32_t v = j; v < p.n_vars; v += 4) p.state[(size_t)v * p.pitch + chain] = lds[v * p.par_stride + cb];
@@ -724,6 +735,12 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
         const uint32_t *h = reinterpret_cast<const uint32_t *>(lds + p.par_hist_off);
         unsigned long long *gc = p.counts + (size_t)variant * p.H;
         flush_rank_hist(p, vd, h, gc, tid, nthr);
+    }
+    if (p.dbg_times && tid == 0) { // measurements only: when this block ran, and where
+        p.dbg_times[blockIdx.x * 4u] = dbg_t0;
+        p.dbg_times[blockIdx.x * 4u + 1u] = __builtin_amdgcn_s_memrealtime();
+        p.dbg_times[blockIdx.x * 4u + 2u] = __builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11));   // HW_ID
+        p.dbg_times[blockIdx.x * 4u + 3u] = __builtin_amdgcn_s_getreg((20) | (0 << 6) | (31 << 11));  // XCC_ID
     }
 }
 
@@ -781,7 +798,9 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
         lim = t > p.log_off ? t - p.log_off : 0u;
         logp = p.log + (size_t)(chain >> 6) * p.log_pitch + (size_t)p.log_off * 64u + lane;
     }
+    const PrioRotor prio; // (wave_prio.h)
     for (uint32_t qi = 0; qi < nq; ++qi) {
+        prio.tick<8>(qi);
         const uint64_t qn = q0 + qi + 1u;
         const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w}, du[4] = {dr.x, dr.y, dr.z, dr.w};
         RecL<SLOTS, PACKED> r[4];
@@ -1156,9 +1175,11 @@ __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const Fa
             }
         }
     };
+    const PrioRotor prio; // (wave_prio.h)
     if constexpr (ROUND_AHEAD) {
         // (the record sets do not swap roles between iterations: 4 rounds per iteration, set A always serves rounds 0 and 2)
         for (uint32_t it = 0; it < n_it; it += 2) {
+            prio.tick<4>(it);
             iteration(it, rA, pwA, rB, pwB);
             if (it + 1u < n_it) {
                 // second iteration of the pair: plan words live in pwB now, the record sets keep their parity
@@ -1167,6 +1188,7 @@ __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const Fa
         }
     } else {
         for (uint32_t it = 0; it < n_it; it += 2) {
+            prio.tick<4>(it);
             iteration(it, rA, pwA, rB, pwB);
             if (it + 1u < n_it) iteration(it + 1u, rB, pwB, rA, pwA);
         }

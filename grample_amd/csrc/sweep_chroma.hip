@@ -23,6 +23,7 @@
 #include "device_layout.h"
 #include "kernels.h"
 #include "philox.h"
+#include "wave_prio.h"
 
 namespace gr {
 
@@ -90,7 +91,9 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
         }
     }
 
+    const PrioRotor prio; // (wave_prio.h)
     for (uint64_t sq = sweep0 >> 2; (sq << 2) < sweep0 + n_sweeps; ++sq) {
+        prio.tick<3>((uint32_t)sq);
         uint32_t U[NSLOT][4];
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
@@ -204,7 +207,9 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
         ones[s] = 0;
         posr[s] = (uint32_t)s < vd.csl_n ? ((lds_u4_t *)(uintptr_t)(recs + (uint32_t)s * 64u * RB))->w : 0u;
     }
+    const PrioRotor prio; // (wave_prio.h)
     for (uint64_t sq = sweep0 >> 2; (sq << 2) < sweep0 + n_sweeps; ++sq) {
+        prio.tick<3>((uint32_t)sq);
         uint32_t U[NSLOT][4];
 #pragma unroll
         for (int s = 0; s < (int)NSLOT; ++s) {

@@ -21,6 +21,7 @@
 #include "device_layout.h"
 #include "kernels.h"
 #include "philox.h"
+#include "wave_prio.h"
 
 namespace gr {
 
@@ -194,7 +195,9 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
         sys_sweep = s_first / vd.n_free;
         sys_pos = (uint32_t)(s_first - sys_sweep * vd.n_free);
     }
+    const PrioRotor prio; // (wave_prio.h: the blocks of a CU progress as equals)
     for (uint32_t g0 = 0; g0 < nq; g0 += 4) {
+        prio.tick<5>(g0);
         uint32_t U[4];
         if (sys) {
 #pragma unroll

@@ -24,6 +24,7 @@
 #include "device_layout.h"
 #include "kernels.h"
 #include "philox.h"
+#include "wave_prio.h"
 
 namespace gr {
 
@@ -284,8 +285,10 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
         const uint32_t w = (uint32_t)sw & 3u;
         return w == 0 ? d.x : w == 1 ? d.y : w == 2 ? d.z : d.w;
     };
+    const PrioRotor prio; // (wave_prio.h: the blocks of a CU progress as equals)
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
+        prio.tick<2>(q_lo);
         const u32x2v sv = plan[q - (step0 >> 2)]; // the quad's four variables, 16 bits each
         const uint32_t sc[4] = {sv[0] & 0xffffu, sv[0] >> 16, sv[1] & 0xffffu, sv[1] >> 16};
         u32x4 dr{0, 0, 0, 0};
