@@ -66,6 +66,7 @@ struct SweepParams {
     uint32_t log_vals;          // bytes per logged step: 1 = the number of ones (all-binary models), else max Card (one count per value)
     uint32_t log_rows;          // rows per 64-chain group in the log (4 when the 4-lane form writes it); this kernel uses the first
     const uint32_t *sys_order;  // GR_FLAG_SCAN_SYSTEMATIC: the sweep order (same pool layout as free_vars), else null
+    uint32_t prio_shift;        // wave_prio.h: the wavefront priority rotates every 2^prio_shift trips of the kernel's loop (>= 32: never)
 };
 
 // Fast binary/memoised path (sweep_bin.hip).  A RECORD is one 64-byte line per
@@ -105,6 +106,7 @@ struct FastParams {
     const uint32_t *recs_par;
     uint32_t par_hist_off, par_tab_off, par_rec_off, par_plan_off, par_scr_off;
     uint32_t *err;               // device error word (bit 0: the dynamic LDS array does not start at LDS address 0)
+    uint32_t prio_shift;         // wave_prio.h: the wavefront priority rotates every 2^prio_shift trips of the kernel's loop (>= 32: never)
     unsigned long long *dbg_times; // measurements only (GR_DEV_BLOCK_TIMES): per block of k_sweep_par4 {start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID}, or null
     uint32_t par_recmode;        // k_sweep_par4 record source: 0 LDS per step, 1 LDS fetched together, 2 global prefetched, other = auto
     uint32_t plan_slots, plan_nfree_max; // k_scan_plan's LDS table: most neighbours of a variable, most selectable variables of a group

@@ -306,7 +306,7 @@ __global__ void __launch_bounds__(256) k_sweep(const SweepParams p) {
     const PrioRotor prio; // (wave_prio.h: the blocks of a CU progress as equals)
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
-        prio.tick<5>(q_lo);
+        prio.tick(q_lo, p.prio_shift);
         uint32_t su[4] = {0, 0, 0, 0}, du[4];
         uint32_t v[4];
         cu32p pg[4];

@@ -178,6 +178,12 @@ struct gr_sampler {
     uint32_t pw4_hist_off = 0, pw4_lds = 0;
     bool dir4 = false;                // step-parallel form of the direct conditional (k_sweep_dir4): Card <= 4, blankets too large to memoise
     bool dir4_vlds = false, dir4_elds = false; // ... with the view tables / the factor entries staged in LDS
+    // wave_prio.h: the wavefront priority of a sweep kernel rotates every 2^shift trips of its loop; GR_DEV_PRIO_SHIFT overrides
+    // the per-kernel default (measurements only; 32 = no rotation)
+    static uint32_t prio_shift(uint32_t dflt) {
+        static const int env = [] { const char *e = getenv("GR_DEV_PRIO_SHIFT"); return e ? atoi(e) : -1; }();
+        return env >= 0 ? (uint32_t)env : dflt;
+    }
     bool sys_wide() const { return sysscan && !chroma && fast && par && wide_ok && !no_wide && !strict_fast && (o.fast_form == 0 || o.fast_form == 8 || o.fast_form == 9); } // the systematic scan on k_sweep_wide
     bool dir4_chain = false;          // ... with chained factor entries (a factor of arity > 4 or with strides past 16 bits: collapse factors)
     // factor entries of variable v's list in the form this sampler uses: one per factor, or one per pair of other scope variables
@@ -819,6 +825,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     launches_last = 0;
     if (updates == 0) return;
     SweepParams p{};
+    p.prio_shift = prio_shift(5);
     p.variants = d_variants.p;
     p.progs = d_progs.p; p.prog_off = d_prog_off.p; p.views = d_views.p; p.free_vars = d_free.p;
     p.cprogs = d_cprogs.p; p.cprog_off = d_cprog_off.p; p.cpt = d_cpt.p;
@@ -864,9 +871,9 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 const uint32_t n_quads = (uint32_t)(((step + n - 1) >> 2) - (step >> 2) + 1);
                 p.scan_vars = d_scan_vars.p; p.scan_pitch = pw4_plan_steps / 4u + 2u;
                 hip_check(launch_scan_vars(a, n_quads, p.scan_pitch, d_scan_vars.p, stream), "k_scan_vars launch");
-                p.lds_hist_off = pw4_hist_off;
+                p.lds_hist_off = pw4_hist_off; p.prio_shift = prio_shift(2); // (a trip of k_sweep_pw4's loop is 4 heavy steps)
                 hip_check(launch_sweep_pw4(p, act / 64u, pw4_lds, stream), "k_sweep_pw4 launch");
-                p.lds_hist_off = lds_hist_off;
+                p.lds_hist_off = lds_hist_off; p.prio_shift = prio_shift(5);
             } else
             hip_check(launch_sweep(p, max_card, cpt && !plain, tab_lds && !plain, pairwise, (o.flags & GR_FLAG_SCAN_PER_CHAIN) != 0, stg,
                                    (act + T - 1) / T, T, lds, stream), "k_sweep launch");
@@ -906,6 +913,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         // quad-unaligned head and tail go through the generic kernel (bit-identical streams), the rest in launches of
         // k_scan_plan + k_sweep_dir4 (16 steps per inner iteration)
         FastParams f{};
+        f.prio_shift = prio_shift(5);
         f.sys_rank = sys ? d_sys_rank.p : nullptr;
         f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p;
         f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p; f.plan_pitch = plan_steps;
@@ -942,6 +950,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         const uint64_t updates = n_updates;
         // quad-unaligned head and tail go through the generic kernel (bit-identical streams)
         FastParams f{};
+        f.prio_shift = prio_shift(5);
         f.sys_rank = sys ? d_sys_rank.p : nullptr;
         f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p;
         f.cpt = d_cpt.p; f.recs = d_recs.p; f.plan = d_plan.p; f.state = d_state.p; f.counts = d_counts.p;
@@ -988,6 +997,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         }
         if (sys && lpc == 4) throw Error(GR_E_STATE, "systematic scan on the 4-lane form (internal error)");
         if (par) lpc_last = lpc;
+        f.prio_shift = prio_shift(strict_fast || !par ? 8u : lpc > 4u ? 4u : 5u); // trips of the kernel's loop per priority rotation (wave_prio.h)
         const uint64_t gran = strict_fast ? 4 : par ? 4u * lpc : 4; // steps per inner iteration of the fast kernels
         uint64_t left = updates;
         const uint64_t head = std::min<uint64_t>(left, (gran - (step % gran)) % gran);
@@ -1057,6 +1067,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         uint64_t left = updates;
         if (chroma) {
             FastParams f{};
+            f.prio_shift = prio_shift(3); // (a trip of the chromatic kernels' loop is 4 sweeps)
             f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p; f.cpt = d_cpt.p;
             f.state = d_state.p; f.counts = d_counts.p;
             f.n_vars = (uint32_t)n_vars; f.H = (uint32_t)H; f.n_chains = act; f.pitch = pitch; f.chains_per_variant = cpv;
@@ -1107,6 +1118,7 @@ void gr_sampler::burn_groups(uint32_t first, uint32_t last, uint32_t updates) {
     use();
     if (dirty) rebuild();
     SweepParams p{};
+    p.prio_shift = prio_shift(5);
     p.variants = d_variants.p;
     p.progs = d_progs.p; p.prog_off = d_prog_off.p; p.views = d_views.p; p.free_vars = d_free.p;
     p.cprogs = d_cprogs.p; p.cprog_off = d_cprog_off.p; p.cpt = d_cpt.p;

@@ -33,9 +33,6 @@
 #ifndef GR_PAR4_PART
 #define GR_PAR4_PART 0
 #endif
-#ifndef GR_PAR4_PRIO_SHIFT
-#define GR_PAR4_PRIO_SHIFT 5 // k_sweep_par4 rotates its wavefront priority every 2^5 quads (wave_prio.h; 3: 8.32e11, 5: 8.40e11, 7: 8.3e11 on the headline)
-#endif
 
 namespace gr {
 
@@ -268,7 +265,7 @@ __global__ void __launch_bounds__(1024) k_sweep_bin(const FastParams p) {
 
     const PrioRotor prio; // (wave_prio.h)
     for (uint32_t qi = 0; qi < nq; ++qi) {
-        prio.tick<8>(qi);
+        prio.tick(qi, p.prio_shift);
         const uint64_t q = q0 + qi;
         if ((qi & (kPlanChunk - 1u)) == kPlanChunk / 2u) {
             // mid-chunk: park the prefetched next chunk in the other half of the ring, fetch the one after it
@@ -718,13 +715,13 @@ __global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
     const PrioRotor prio; // (wave_prio.h: the blocks of a CU progress as equals)
     if constexpr (RECMODE == 2) {
         for (uint32_t g0 = 0; g0 < nq; g0 += 8) {
-            prio.tick<GR_PAR4_PRIO_SHIFT>(g0);
+            prio.tick(g0, p.prio_shift);
             if (!run(g0, rA, pwA, rB, pwB)) break;
             if (g0 + 4u < nq && !run(g0 + 4u, rB, pwB, rA, pwA)) break;
         }
     } else {
         for (uint32_t g0 = 0; g0 < nq; g0 += 4) {
-            prio.tick<GR_PAR4_PRIO_SHIFT>(g0);
+            prio.tick(g0, p.prio_shift);
             if (!run(g0, rA, pwA, rB, pwB)) break;
         }
     }
@@ -800,7 +797,7 @@ __global__ void __launch_bounds__(256) k_sweep_strict(const FastParams p) {
     }
     const PrioRotor prio; // (wave_prio.h)
     for (uint32_t qi = 0; qi < nq; ++qi) {
-        prio.tick<8>(qi);
+        prio.tick(qi, p.prio_shift);
         const uint64_t qn = q0 + qi + 1u;
         const uint32_t su[4] = {sc.x, sc.y, sc.z, sc.w}, du[4] = {dr.x, dr.y, dr.z, dr.w};
         RecL<SLOTS, PACKED> r[4];
@@ -1179,7 +1176,7 @@ __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const Fa
     if constexpr (ROUND_AHEAD) {
         // (the record sets do not swap roles between iterations: 4 rounds per iteration, set A always serves rounds 0 and 2)
         for (uint32_t it = 0; it < n_it; it += 2) {
-            prio.tick<4>(it);
+            prio.tick(it, p.prio_shift);
             iteration(it, rA, pwA, rB, pwB);
             if (it + 1u < n_it) {
                 // second iteration of the pair: plan words live in pwB now, the record sets keep their parity
@@ -1188,7 +1185,7 @@ __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const Fa
         }
     } else {
         for (uint32_t it = 0; it < n_it; it += 2) {
-            prio.tick<4>(it);
+            prio.tick(it, p.prio_shift);
             iteration(it, rA, pwA, rB, pwB);
             if (it + 1u < n_it) iteration(it + 1u, rB, pwB, rA, pwA);
         }

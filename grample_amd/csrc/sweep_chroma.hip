@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
 
     const PrioRotor prio; // (wave_prio.h)
     for (uint64_t sq = sweep0 >> 2; (sq << 2) < sweep0 + n_sweeps; ++sq) {
-        prio.tick<3>((uint32_t)sq);
+        prio.tick((uint32_t)sq, p.prio_shift);
         uint32_t U[NSLOT][4];
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s) {
@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
     }
     const PrioRotor prio; // (wave_prio.h)
     for (uint64_t sq = sweep0 >> 2; (sq << 2) < sweep0 + n_sweeps; ++sq) {
-        prio.tick<3>((uint32_t)sq);
+        prio.tick((uint32_t)sq, p.prio_shift);
         uint32_t U[NSLOT][4];
 #pragma unroll
         for (int s = 0; s < (int)NSLOT; ++s) {

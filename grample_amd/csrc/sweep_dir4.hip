@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) k_sweep_dir4(const FastParams p) {
     }
     const PrioRotor prio; // (wave_prio.h: the blocks of a CU progress as equals)
     for (uint32_t g0 = 0; g0 < nq; g0 += 4) {
-        prio.tick<5>(g0);
+        prio.tick(g0, p.prio_shift);
         uint32_t U[4];
         if (sys) {
 #pragma unroll

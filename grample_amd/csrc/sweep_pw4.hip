@@ -288,7 +288,7 @@ __global__ void __launch_bounds__(256) k_sweep_pw4(const SweepParams p) {
     const PrioRotor prio; // (wave_prio.h: the blocks of a CU progress as equals)
     for (uint64_t q = step0 >> 2; (q << 2) < step1; ++q) {
         const uint32_t q_lo = (uint32_t)q, q_hi = (uint32_t)(q >> 32);
-        prio.tick<2>(q_lo);
+        prio.tick(q_lo, p.prio_shift);
         const u32x2v sv = plan[q - (step0 >> 2)]; // the quad's four variables, 16 bits each
         const uint32_t sc[4] = {sv[0] & 0xffffu, sv[0] >> 16, sv[1] & 0xffffu, sv[1] >> 16};
         u32x4 dr{0, 0, 0, 0};

@@ -15,11 +15,11 @@ namespace gr {
 struct PrioRotor {
     uint32_t slot; // HW_ID.wave_id: which of the SIMD's wavefront slots this wavefront sits in (scalar)
     __device__ __forceinline__ PrioRotor() : slot((uint32_t)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 3u) {}
-    // call with a wave-uniform loop counter; the priority changes when its low SHIFT bits are zero (all scalar work)
-    template <int SHIFT>
-    __device__ __forceinline__ void tick(const uint32_t it) const {
-        if ((it & ((1u << SHIFT) - 1u)) == 0u) {
-            const uint32_t pr = ((it >> SHIFT) + slot) & 3u;
+    // call with a wave-uniform loop counter; the priority changes when its low `shift` bits are zero (all scalar work);
+    // shift >= 32: never (the kernels take it from their parameters: the host picks the period per kernel family)
+    __device__ __forceinline__ void tick(const uint32_t it, const uint32_t shift) const {
+        if (shift < 32u && (it & ((1u << shift) - 1u)) == 0u) {
+            const uint32_t pr = ((it >> shift) + slot) & 3u;
             if (pr == 0u) __builtin_amdgcn_s_setprio(0);
             else if (pr == 1u) __builtin_amdgcn_s_setprio(1);
             else if (pr == 2u) __builtin_amdgcn_s_setprio(2);
