@@ -348,6 +348,27 @@ def _pairwise_big_card_model(rng, n=24):
     return SimpleNamespace(card=card, scopes=scopes, tables=tables, fixed=fixed)
 
 
+def test_results_do_not_depend_on_wavefront_priority():
+    """wave_prio.h rotates the issue priority of every sweep kernel's wavefronts (the blocks of a CU then finish together: +11 % on
+    the headline).  Priorities only reorder the issue of independent wavefronts, so nothing may depend on them: counts and states of
+    one run per kernel family (4-lane, wide, chromatic, strict, chain per lane, collapsed groups, value-parallel, step-parallel,
+    generic) are the same without rotation (GR_DEV_PRIO_SHIFT=32), rotating every loop trip (0) and with the defaults."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for shift in ("32", "0", None):
+        env = dict(os.environ)
+        env.pop("GR_DEV_PRIO_SHIFT", None)
+        if shift is not None:
+            env["GR_DEV_PRIO_SHIFT"] = shift
+        r = subprocess.run([sys.executable, os.path.join(root, "scripts", "prio_hash.py")], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        outs.append(r.stdout)
+    assert outs[0] == outs[1] == outs[2] and len(outs[0].strip().splitlines()) == 10
+    assert {int(line.split()[4]) for line in outs[0].strip().splitlines()} >= {0, 2, 3, 5, 6, 8, 9}
+
+
 def test_cross_form_fuzz():
     """scripts/fuzz_forms.py: 32 random models of four shapes (large-Card pairwise, sparse binary, medium-blanket binary, small
     mixed cards with arity up to 4, evidence, near-zero entries) through every kernel form the library can be steered into --
