@@ -1,3 +1,5 @@
+"""Per-block run times of ONE k_sweep_par4 launch (Grids_13, 65 536 chains = 4 blocks per CU): GR_DEV_BLOCK_TIMES makes the library write
+{block, start, end (s_memrealtime, 100 MHz), HW_ID, XCC_ID} of the last launch to a file.  profiles/r03_block_times.txt: before / after wave_prio.h."""
 import os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import grample_amd as g
