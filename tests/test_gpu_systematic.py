@@ -187,6 +187,39 @@ def test_systematic_plan_kernels_with_collapsed_groups(res_dir, name, path):
     assert out[0][4].sum() + out[0][5].sum() == 768 * 150  # every update of the window lands in one half
 
 
+@pytest.mark.parametrize("name,chains,path", [("Grids_13.uai", 65536, 9), ("ObjectDetection_13.uai", 32768, 6), ("CSP_13.uai", 32768, 8),
+                                               ("Promedus_14.uai", 32768, 3), ("Segmentation_11.uai", 32768, 9)])
+def test_systematic_full_size_properties(res_dir, name, chains, path):
+    """The systematic scan at the BASELINE sizes, size-independent properties: conservation, every selectable variable updated
+    once per sweep, determinism, independence of the launch chunking (launches that start and end inside a sweep) and of the
+    split of the chains over devices (two shards with chain_offset == one sampler)."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    n = m.n_vars
+    upd = 6 * n
+
+    def run(chunks, nch=chains, off=0):
+        s = g.HIPChains(m, nch, seed=7, chain_offset=off, flags=SYS)
+        s.BurnIn(n + 3)
+        for c in chunks:
+            s.Advance(c)
+        return s
+
+    a = run([upd])
+    assert a.info()["path"] == path
+    ca = a.counts()[0]
+    assert int(ca.sum()) == chains * upd == a.TotalSampleCount()
+    cards = m.cards()
+    hoff = np.concatenate([[0], np.cumsum(cards)])
+    per_var = np.array([ca[hoff[v]:hoff[v + 1]].sum() for v in range(n)])
+    assert set(per_var.tolist()) == {chains * 6}  # 6 whole sweeps counted (no evidence in these models): every variable 6 times per chain
+    assert np.array_equal(ca, run([upd]).counts()[0])
+    assert np.array_equal(ca, run([7, upd - 7 - 2 * n - 1, 2 * n + 1]).counts()[0])
+    h = chains // 2
+    parts = [run([upd], h, k * h) for k in range(2)]
+    assert np.array_equal(ca, parts[0].counts()[0] + parts[1].counts()[0])
+    assert np.array_equal(a.LastSample(h + 5), parts[1].LastSample(5))
+
+
 def test_systematic_flag_rules(res_dir):
     m = g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai"))
     with pytest.raises(g.GrError):
