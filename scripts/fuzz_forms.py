@@ -26,6 +26,10 @@ def model(rng, kind):
         n = int(rng.integers(40, 200))
         card = [2] * n
         arity = 4
+    elif kind == "tiny_binary":         # 1..6 binary variables: sweeps shorter than a quad / a round of the wide forms
+        n = int(rng.integers(1, 7))
+        card = [2] * n
+        arity = 2
     elif kind == "dense_small":         # k_sweep_dir4 territory: Card 2..4, blankets too large to memoise
         n = int(rng.integers(20, 90))
         card = [int(rng.choice([2, 3, 4, 4])) for _ in range(n)]
@@ -40,6 +44,8 @@ def model(rng, kind):
     nf = int(n * (rng.uniform(3.0, 6.0) if kind == "dense_small" else rng.uniform(0.8, 2.5 if kind != "binary_medium" else 1.2)))
     for _ in range(nf):
         k = int(rng.integers(2, arity + 1))
+        if n < 2:
+            break
         sc = [int(x) for x in rng.choice(n, min(k, n), replace=False)]
         size = int(np.prod([card[v] for v in sc]))
         t = np.exp(rng.uniform(-3, 3, size))
@@ -66,7 +72,7 @@ def run(m, chains, seed, off, collapse=None, **kw):
 def main():
     n_models = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    kinds = ["bigcard_pairwise", "binary_sparse", "binary_medium", "mixed", "dense_small"]
+    kinds = ["bigcard_pairwise", "binary_sparse", "binary_medium", "mixed", "dense_small", "tiny_binary"]
     seen = {}
     for i in range(n_models):
         kind = kinds[i % len(kinds)]
