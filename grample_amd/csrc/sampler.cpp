@@ -184,6 +184,21 @@ struct gr_sampler {
         static const int env = [] { const char *e = getenv("GR_DEV_PRIO_SHIFT"); return e ? atoi(e) : -1; }();
         return env >= 0 ? (uint32_t)env : dflt;
     }
+    // Lanes per chain of the step-parallel form for a launch over `groups` 64-chain groups: 4 (k_sweep_par4), or 8 / 16 (k_sweep_wide)
+    // while the launch would otherwise leave SIMDs short of wavefronts.
+    // measured (scripts/dev_wide.py -> profiles/r03_dev_wide.txt): 16 lanes pay while 16 x groups <= 4 096 wavefronts AND either
+    // the block's LDS footprint lets a CU hold four of them or the whole launch fits the chip as one-wavefront blocks (each
+    // with its own copy of the tables: the first rounds of an adaptive run); 8 lanes while 8 x groups <= 4 096; beyond that the
+    // 4-lane form has the chip full and the wider forms' extra passes only cost
+    uint32_t auto_lpc(uint32_t groups) const {
+        if (!(par && wide_ok && !no_wide)) return 4;
+        const uint32_t fit = kLdsBudget / std::max(par_rec_off, 1u);
+        if (o.fast_form == 8 || o.fast_form == 10) return 8;
+        if (o.fast_form == 9) return 16;
+        if (o.fast_form == 0 && groups * 16u <= 4096u && (fit >= 4u || groups * 16u <= 256u * fit)) return 16;
+        if (o.fast_form == 0 && groups * 8u <= 4096u) return 8;
+        return 4;
+    }
     bool sys_wide() const { return sysscan && !chroma && fast && par && wide_ok && !no_wide && !strict_fast && (o.fast_form == 0 || o.fast_form == 8 || o.fast_form == 9); } // the systematic scan on k_sweep_wide
     bool dir4_chain = false;          // ... with chained factor entries (a factor of arity > 4 or with strides past 16 bits: collapse factors)
     // factor entries of variable v's list in the form this sampler uses: one per factor, or one per pair of other scope variables
@@ -979,20 +994,12 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         f.par_plan_off = par_plan_off; f.par_scr_off = par_scr_off;
         // Lanes per chain of the step-parallel form for THIS launch: 4 (k_sweep_par4), or 8 / 16 (k_sweep_wide) while the launch would
         // otherwise leave SIMDs short of wavefronts.  Wider rounds cost more re-gather passes per update (Grids: x1.13 with 8 lanes,
-        // x1.3 with 16), so: 16 lanes up to 2 wavefronts per SIMD (1 024 SIMDs), 8 lanes up to 4; logged windows (gr_advance_chain)
-        // always run the 4-lane form.  All forms give the same results bit for bit, so launches of a run may differ.
+        // x1.3 with 16), so: 16 lanes up to 2 wavefronts per SIMD (1 024 SIMDs), 8 lanes up to 4 (auto_lpc); a logged window (gr_advance_chain)
+        // runs the form gr_advance_chain laid its log out for.  All forms give the same results bit for bit, so launches of a run may differ.
         uint32_t lpc = 4;
-        if (par && wide_ok && !no_wide && !cur_log && !cur_limit) {
-            const uint32_t groups = act / 64u;
-            // measured (scripts/dev_wide.py -> profiles/r03_dev_wide.txt): 16 lanes pay while 16 x groups <= 4 096 wavefronts AND either
-            // the block's LDS footprint lets a CU hold four of them or the whole launch fits the chip as one-wavefront blocks (each
-            // with its own copy of the tables: the first rounds of an adaptive run); 8 lanes while 8 x groups <= 4 096; beyond that the
-            // 4-lane form has the chip full and the wider forms' extra passes only cost
-            const uint32_t fit = kLdsBudget / std::max(par_rec_off, 1u);
-            if (o.fast_form == 8 || o.fast_form == 10) lpc = 8;
-            else if (o.fast_form == 9) lpc = 16;
-            else if (o.fast_form == 0 && groups * 16u <= 4096u && (fit >= 4u || groups * 16u <= 256u * fit)) lpc = 16;
-            else if (o.fast_form == 0 && groups * 8u <= 4096u) lpc = 8;
+        if (par && wide_ok && !no_wide) {
+            if (cur_log || cur_limit) lpc = cur_log_rows > 4u ? cur_log_rows : 4u; // a logged window: gr_advance_chain chose (one log row per wavefront)
+            else lpc = auto_lpc(act / 64u);
             if (sys && lpc == 4) lpc = 8; // (the systematic scan exists in the wide forms only: k_sweep_par4 is left as it is)
         }
         if (sys && lpc == 4) throw Error(GR_E_STATE, "systematic scan on the 4-lane form (internal error)");
@@ -1899,9 +1906,15 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
         bool binary = true;
         for (uint32_t g = 0; g < (s->o.n_variants > 1 ? s->n_active : 1u) && binary; ++g)
             for (uint32_t v : s->image[g].free_vars) binary = binary && s->card[v] == 2;
-        const uint32_t rows = (s->par || s->dir4 || s->pw4) ? 4u : 1u; // the 4-lane forms log one row per wavefront (16 chains)
+        uint32_t rows = (s->par || s->dir4 || s->pw4) ? 4u : 1u; // the 4-lane forms log one row per wavefront (16 chains)
         const uint32_t log_vals = binary ? 1u : (uint32_t)s->max_card;
         const uint64_t pitch = (L * log_vals + 15u) & ~15ull;
+        // ... and the 8 / 16-lane form one per wavefront of 8 / 4 chains, while the window is short of wavefronts (an adaptive run's
+        // first rounds) and the log stays small
+        if (s->fast && s->par && binary && !s->strict_fast) {
+            const uint32_t lpc = s->auto_lpc(n_groups);
+            if (lpc > 4u && (uint64_t)n_groups * lpc * pitch <= (2ull << 30)) rows = lpc;
+        }
         const bool logging = (binary || !s->fast) && pitch <= 0xfffffff0ull && (uint64_t)n_groups * rows * pitch <= (16ull << 30);
         const size_t nH = (size_t)s->o.n_variants * s->H;
         DevBuf<unsigned char> &d_log = s->d_log;

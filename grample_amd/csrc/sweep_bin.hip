@@ -960,7 +960,7 @@ hipError_t launch_sweep_par4_p4(const FastParams &p, int slots, uint32_t blocks,
 //             (j1 j0), and lane slot (j1 j0 | j_hi) ends up with word (j1 j0) of quads Q0 + 4 k' + .. for the rounds k' = 0 .. 3
 //   iteration 4 rounds of LPC steps (one Philox call per lane); records and plan words from global memory, one iteration ahead
 // Counting, records, threshold tables (LDS, global, split) and the commit order are k_sweep_par4's: bit-identical results.
-// No draw log: gr_advance_chain windows run the 4-lane form (same results, so the forms mix freely).
+// Draw log (MODE 2): one row per wavefront; gr_advance_chain picks this form for a window by the same rule as any launch.
 constexpr uint32_t kWideOffMask = 0x03ffffc0u; // plan word of the wide form: record offset (< 64 MiB, multiple of 64) in bits 6..25,
                                                // level in bits 0..3, highest level of the round in bits 26..29, bits 30 / 31 as kPlanDepsBit / kPlanLevelBit
 
@@ -1035,9 +1035,12 @@ __global__ void __launch_bounds__(256) k_scan_plan_wide(const FastParams p) {
 
 // DENSE (8 lanes per chain, 4-slot records, tables in LDS): records one round ahead and at most 64 registers, so that a SIMD holds 8
 // wavefronts -- 65 536 chains as 8 192 resident wavefronts (experiment: fast_form 10)
-template <int LPC, int SLOTS, int MODE, int TABG, bool DENSE = false> // MODE 0: burn-in, 1: count
+// MODE 2 (gr_advance_chain's windows while wavefronts are what a launch lacks -- the first rounds of an adaptive run): count + draw
+// log, one row per wavefront (LPC rows of W chains per 64-chain group: SweepParams::log_rows = LPC), one byte per step = the ones among
+// the wavefront's W chains; a group executes only the steps below its own stopping time (p.limit), checked per step.
+template <int LPC, int SLOTS, int MODE, int TABG, bool DENSE = false> // MODE 0: burn-in, 1: count, 2: count + draw log
 __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const FastParams p) { // (4 wavefronts per SIMD: <= 128 registers)
-    constexpr bool COUNT = MODE != 0, PACKED = true;
+    constexpr bool COUNT = MODE != 0, LOG = MODE == 2, PACKED = true;
     constexpr uint32_t W = 64u / LPC, E = LPC / 4u;
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, nthr = blockDim.x;
@@ -1112,7 +1115,16 @@ __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const Fa
 
     // GR_FLAG_SCAN_SYSTEMATIC (p.sys_rank set): the plan follows the sweep order and update t of a chain takes word (sweep & 3) of
     // philox_sys_draw(sweep = t / n, pos = t mod n, chain) -- one Philox call per step.  My steps are LPC apart.
-    const bool sys = !DENSE && p.sys_rank != nullptr;
+    unsigned char *logrow = nullptr; // LOG: my wavefront's row of the draw log, and the group's stopping time inside this launch
+    uint32_t lim = 0xffffffffu;
+    if constexpr (LOG) {
+        if (p.log) logrow = p.log + (size_t)(group * LPC + wave) * p.log_pitch + p.log_off;
+        if (p.limit) {
+            const uint32_t t = p.limit[group];
+            lim = t > p.log_off ? t - p.log_off : 0u;
+        }
+    }
+    const bool sys = !DENSE && !LOG && p.sys_rank != nullptr;
     uint64_t sys_sweep = 0;
     uint32_t sys_pos = 0;
     if (sys) {
@@ -1148,9 +1160,11 @@ __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const Fa
             if constexpr (ROUND_AHEAD) fetch((k & 1) ? rc[0] : rx[0], k < 3 ? pwc[k + 1] : pwx[0]);
             const RecL<SLOTS, PACKED> r = ROUND_AHEAD ? ((k & 1) ? rx[0] : rc[0]) : rc[ROUND_AHEAD ? 0 : k];
             const uint32_t pw = pwc[k];
+            const uint32_t sidx = (it * 4u + (uint32_t)k) * LPC + j; // step index inside this launch
+            const bool runs = !LOG || sidx < lim;                     // (LOG: steps past the group's stopping time leave it untouched)
             const bool val = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
             unsigned long long drawn = __ballot(val);
-            if (pw < kPlanLevelBit) lds[r.h.x + cb] = val ? (unsigned char)1 : (unsigned char)0; // level 0: commit in the first pass
+            if (pw < kPlanLevelBit && runs) lds[r.h.x + cb] = val ? (unsigned char)1 : (unsigned char)0; // level 0: commit in the first pass
             if (__any(pw >= kPlanDepsBit)) { // the round has steps that do not commute (uniform: the same bits in all its words)
                 const uint32_t lv = pw & 15u;
                 const uint32_t maxlv = (uni_b(pw) >> 26) & 15u;
@@ -1159,16 +1173,18 @@ __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const Fa
                     // compiler -- see k_sweep_par4)
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                     const bool v2 = sample_l<SLOTS, PACKED, TABG>(r, lds_c, tabp, U[k]) != 0u;
-                    if (lv == level) lds[r.h.x + cb] = v2 ? (unsigned char)1 : (unsigned char)0;
+                    if (lv == level && runs) lds[r.h.x + cb] = v2 ? (unsigned char)1 : (unsigned char)0;
                     const unsigned long long mine = __ballot(lv == level);
                     drawn = (drawn & ~mine) | (__ballot(v2) & mine);
                 }
             }
             if constexpr (COUNT) {
                 const uint32_t s1 = (uint32_t)__builtin_popcount(((uint32_t)drawn & rm_lo) | ((uint32_t)(drawn >> 32) & rm_hi));
-                if (tail)
+                if (tail && runs) {
                     __hip_atomic_fetch_add(reinterpret_cast<__attribute__((address_space(3))) unsigned long long *>((uintptr_t)r.h.y),
                                            ((unsigned long long)s1 << 32) | (unsigned long long)(W - s1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (LOG && logrow) logrow[sidx] = (unsigned char)s1;
+                }
             }
         }
     };
@@ -1176,6 +1192,7 @@ __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const Fa
     if constexpr (ROUND_AHEAD) {
         // (the record sets do not swap roles between iterations: 4 rounds per iteration, set A always serves rounds 0 and 2)
         for (uint32_t it = 0; it < n_it; it += 2) {
+            if (LOG && it * (4u * LPC) >= lim) break; // the group has finished its AdvanceChain
             prio.tick(it, p.prio_shift);
             iteration(it, rA, pwA, rB, pwB);
             if (it + 1u < n_it) {
@@ -1185,6 +1202,7 @@ __global__ void __launch_bounds__(64 * LPC, DENSE ? 8 : 4) k_sweep_wide(const Fa
         }
     } else {
         for (uint32_t it = 0; it < n_it; it += 2) {
+            if (LOG && it * (4u * LPC) >= lim) break; // the group has finished its AdvanceChain
             prio.tick(it, p.prio_shift);
             iteration(it, rA, pwA, rB, pwB);
             if (it + 1u < n_it) iteration(it + 1u, rB, pwB, rA, pwA);
@@ -1208,9 +1226,10 @@ static hipError_t launch_wide_t(const FastParams &p, uint32_t groups, uint32_t l
         hipLaunchKernelGGL(kern, dim3(p.par_spread ? groups * LPC : groups), dim3(p.par_spread ? 64 : 64 * LPC), lds, s, p);
         return hipGetLastError();
     };
-    if (p.tab_global && p.par_tab_words) return p.counting ? go(&k_sweep_wide<LPC, SLOTS, 1, 2>) : go(&k_sweep_wide<LPC, SLOTS, 0, 2>);
-    if (p.tab_global) return p.counting ? go(&k_sweep_wide<LPC, SLOTS, 1, 1>) : go(&k_sweep_wide<LPC, SLOTS, 0, 1>);
-    return p.counting ? go(&k_sweep_wide<LPC, SLOTS, 1, 0>) : go(&k_sweep_wide<LPC, SLOTS, 0, 0>);
+    const bool log = p.counting && (p.log || p.limit);
+    if (p.tab_global && p.par_tab_words) return log ? go(&k_sweep_wide<LPC, SLOTS, 2, 2>) : p.counting ? go(&k_sweep_wide<LPC, SLOTS, 1, 2>) : go(&k_sweep_wide<LPC, SLOTS, 0, 2>);
+    if (p.tab_global) return log ? go(&k_sweep_wide<LPC, SLOTS, 2, 1>) : p.counting ? go(&k_sweep_wide<LPC, SLOTS, 1, 1>) : go(&k_sweep_wide<LPC, SLOTS, 0, 1>);
+    return log ? go(&k_sweep_wide<LPC, SLOTS, 2, 0>) : p.counting ? go(&k_sweep_wide<LPC, SLOTS, 1, 0>) : go(&k_sweep_wide<LPC, SLOTS, 0, 0>);
 }
 
 template <int LPC>

@@ -1,0 +1,12 @@
+import os, sys, time
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT)
+import grample_amd as g
+m = g.Model.NewModelFromFile(os.path.join(ROOT, "tests/golden/res/Segmentation_11.uai"), True)
+s = g.HIPChains(m, 128 * 256, n_variants=128, seed=42)
+s.set_active_groups(2); s.BurnIn(2000)
+tot = 0
+for r in range(34):
+    L = s.AdvanceChain(2000); k = s.info()["kernel_ms_last"]; tot += k
+    print(r, "groups", s.active_groups(), "window", L, "kernel ms %.1f" % k, "rate %.3e" % (s.active_groups() * 256 * L / (k * 1e-3)), "lanes", s.info()["block_threads"] // 64, "cum %.0f" % tot, flush=True)
+    s.Adapt(4)

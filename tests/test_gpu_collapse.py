@@ -570,6 +570,36 @@ def test_advance_chain_per_chain_scan_and_global_state(res_dir, model, cw, chain
         assert s.TotalSampleCount() < chains * (s.info()["step"] - 7)  # the chains did stop at different times
 
 
+@pytest.mark.parametrize("name,chains,groups,lanes", [("Grids_13.uai", 256, 1, 16), ("Grids_11.uai", 8192, 1, 16), ("Segmentation_11.uai", 2048, 8, 16), ("Segmentation_11.uai", 8192, 32, 8),
+                                                      ("Promedus_14.uai", 1024, 2, 16)])
+def test_advance_chain_on_the_wide_form_equals_four_lanes(res_dir, name, chains, groups, lanes):
+    """gr_advance_chain while the window is short of wavefronts (the first rounds of an adaptive run) runs k_sweep_wide with the draw log
+    -- one log row per wavefront of 8 / 4 chains, the group's stopping time checked per step.  Same window, counts, states and ring
+    halves as the 4-lane form (fast_form 3 = every automatic choice but the wide form), collapsed groups included."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    out = []
+    for form in (0, 3):
+        s = g.HIPChains(m, chains, n_variants=groups, seed=23, fast_form=form)
+        cv = []
+        for k in range(1, groups):
+            try:
+                cv.append(s.Collapse(k, -1)[0])
+            except g.GrError:  # (the reference's own refusal for a variable without neighbours: the group keeps the base model; same pick in both runs)
+                cv.append(None)
+        s.BurnIn(77)
+        L1 = s.AdvanceChain(30)
+        i = s.info()
+        a, b, cw = s.window_halves()
+        L2 = s.AdvanceChain(12)
+        a2, b2, _ = s.window_halves()
+        out.append((i["path"], i["block_threads"] // 64, cv, L1, L2, s.counts(), s.checkpoint()["states"], a, b, a2, b2))
+        s.close()
+    assert out[0][0] == out[1][0] == 3 and out[0][1] == lanes and out[1][1] == 4
+    assert out[0][2] == out[1][2] and out[0][3] == out[1][3] and out[0][4] == out[1][4]
+    for k in range(5, 11):
+        assert np.array_equal(out[0][k], out[1][k]), k
+
+
 def test_advance_chain_adaptive_flow_and_fallbacks(res_dir):
     """`--sampler adaptive` with the reference's own window length (root.go:476-479 -> chain.go:180-218):
     ring halves are per group, groups activated later get theirs, and a model with Card > 2 falls back to the
