@@ -452,7 +452,10 @@ __device__ __forceinline__ uint32_t table_l(const RecL<SLOTS, PACKED> &r, const 
 // words of the pool (the small tables: compiled_model.cpp orders the pool by table size) are staged in LDS, the rest is read
 // from global memory; each record says where its table lives.
 template <int SLOTS, bool PACKED, int MODE, int RECMODE, int TABG = 0> // MODE 0: burn-in, 1: count, 2: count + draw log (gr_advance_chain)
-__global__ void __launch_bounds__(256) k_sweep_par4(const FastParams p) {
+// (launch bounds: the instantiations of the small-blanket models -- Grids: 98 registers -- are held to 96, so that a CU takes FIVE blocks
+// when a launch has them: 81 920 chains 5.9e11 -> 9.1e11, 66 560 chains 4.8e11 -> 7.4e11; at 65 536 chains -- 4 blocks per CU by the chain
+// count -- nothing changes (8.4e11).  The logged form would spill 21 registers and keeps its 4.)
+__global__ void __launch_bounds__(256, (SLOTS <= 4 && TABG == 0 && RECMODE == 2 && MODE != 2) ? 5 : 1) k_sweep_par4(const FastParams p) {
     constexpr bool COUNT = MODE != 0, LOG = MODE == 2;
     extern __shared__ __align__(16) unsigned char lds[];
     // Block shape: 256 lanes = one 64-chain scan group (4 wavefronts of 16 chains), or -- "spread", when the launch has
