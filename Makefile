@@ -14,7 +14,13 @@ OBJS := $(OBJDIR)/kernels.o $(OBJDIR)/kernels_1.o $(OBJDIR)/kernels_2.o $(OBJDIR
 
 TOOL := tools/grample_hip_sample
 
-all: $(LIB) oracle $(TOOL)
+all: $(LIB) oracle $(TOOL) ubench
+
+# stand-alone micro-benchmarks behind bench.py's roofline and DESIGN.md (issue rates; byte state vs bit-packed state)
+UBENCH := scripts/ubench/issue_rate.bin scripts/ubench/state_form.bin
+ubench: $(UBENCH)
+scripts/ubench/%.bin: scripts/ubench/%.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -o $@ $<
 
 # C++ host driver above the C ABI (links nothing but the library)
 $(TOOL): tools/grample_hip_sample.cpp include/grample_hip.h $(LIB)
@@ -66,4 +72,4 @@ clean:
 	rm -rf build $(LIB) $(TOOL)
 	$(MAKE) -s -C oracle clean
 
-.PHONY: all oracle clean
+.PHONY: all oracle clean ubench
