@@ -168,6 +168,20 @@ struct gr_sampler {
     uint32_t chroma_row = 0, chroma_tab_off = 0, chroma_hist_off = 0, chroma_rec_off = 0, chroma_lds = 0, chroma_nslot = 0, sys_n_free = 0, chroma_wpb = 4;
     DevBuf<uint32_t> d_sys_order, d_sys_pos, d_sys_rank, d_chroma_slots, d_recs_chroma;
     DevBuf<unsigned long long> d_dbg; // GR_DEV_BLOCK_TIMES (measurements only)
+    // Plan-ahead for k_sweep_par4: the scan plan of the NEXT launch is computed on a second stream while the current sweep runs (a CU that
+    // holds 4 blocks of the sweep has a fifth wavefront slot free), into the other of two plan buffers; across calls the next call's
+    // first launch is guessed to repeat this call's (a caller's loop of equal gr_advance calls) and checked before use.
+    hipStream_t pstream = nullptr;
+    hipEvent_t ev_plan = nullptr, ev_pre = nullptr;   // the plan-ahead kernel has finished / main-stream work enqueued before the current sweep
+    DevBuf<uint32_t> d_plan_b;                         // the second plan buffer (d_plan is the first)
+    int ahead_buf = -1;                                // buffer holding the plan computed ahead (-1: none), for steps [ahead_step0, + ahead_n) of ahead_act chains
+    uint64_t ahead_step0 = 0;
+    uint32_t ahead_n = 0, ahead_act = 0;
+    bool ahead_inflight = false;                       // ev_plan has been recorded and not yet waited for by the main stream
+    void plan_quiesce() {                              // before anything frees or rewrites what the plan-ahead kernel reads or writes
+        if (pstream) (void)hipStreamSynchronize(pstream);
+        ahead_buf = -1; ahead_inflight = false;
+    }
     bool no_wide = false;             // fast_form 3: every automatic choice, but never the wide form (measurements)
     bool wide_ok = false;             // ... the 8 / 16 lanes-per-chain form (k_sweep_wide) may take its place when wavefronts are what a launch lacks
     uint32_t lpc_last = 4;            // lanes per chain of the last step-parallel launch (gr_sampler_get_info)
@@ -259,6 +273,9 @@ struct gr_sampler {
 
     ~gr_sampler() {
         if (stream) (void)hipStreamSynchronize(stream); // a failed call may have left copies in flight that use the arena
+        if (pstream) { (void)hipStreamSynchronize(pstream); (void)hipStreamDestroy(pstream); }
+        if (ev_plan) (void)hipEventDestroy(ev_plan);
+        if (ev_pre) (void)hipEventDestroy(ev_pre);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -601,6 +618,7 @@ void gr_sampler::configure_impl(bool try_strict_fast) {
 // memoised conditional tables on the device.
 void gr_sampler::rebuild() {
     use();
+    plan_quiesce(); // (the pools the plan-ahead kernel reads are about to be replaced)
     configure();
     std::vector<uint32_t> progs, prog_off, freev, cprogs, cprog_off, pprogs, pprog_off, vprogs, vprog_off;
     pairwise = true;
@@ -856,6 +874,10 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     p.sequential = (o.flags & GR_FLAG_SEQUENTIAL) ? 1u : 0u;
     p.lds_hist_off = lds_hist_off; p.lds_tab_off = lds_tab_off;
     hip_check(hipEventRecord(ev0, stream), "hipEventRecord");
+    if (ahead_inflight) { // whatever runs next may use the plan buffers: the plan computed ahead must have landed
+        hip_check(hipStreamWaitEvent(stream, ev_plan, 0), "hipStreamWaitEvent");
+        ahead_inflight = false;
+    }
     auto generic = [&](uint64_t n_total) {
         uint64_t left = n_total;
         const bool use_pw4 = pw4;
@@ -953,6 +975,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
             f.n_steps = n;
             f.log = cur_log; f.log_pitch = cur_log_pitch; f.log_off = (uint32_t)(step - cur_log_step0); f.limit = cur_limit; f.log_vals = cur_log_vals;
+            ahead_buf = -1; // (this plan goes into the first buffer)
             hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
             hip_check(launch_sweep_dir4(f, max_card, dir4_vlds, dir4_elds, dir4_chain, act / 64u, dir_lds, stream), "k_sweep_dir4 launch");
             step += n; left -= n; launches_last++;
@@ -1004,6 +1027,9 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         }
         if (sys && lpc == 4) throw Error(GR_E_STATE, "systematic scan on the 4-lane form (internal error)");
         if (par) lpc_last = lpc;
+        uint32_t first_n = 0;             // plan-ahead: this call's first launch
+        FastParams plan_ahead{};          // ... and the plan kernel to launch behind the current sweep
+        bool plan_ahead_pending = false;
         f.prio_shift = prio_shift(strict_fast || !par ? 8u : lpc > 4u ? 4u : 5u); // trips of the kernel's loop per priority rotation (wave_prio.h)
         const uint64_t gran = strict_fast ? 4 : par ? 4u * lpc : 4; // steps per inner iteration of the fast kernels
         uint64_t left = updates;
@@ -1037,6 +1063,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 // CU's LDS pipe, as for the 4-lane form); else 64 x lpc lanes per block
                 // ... and the CUs' LDS holds all of those blocks at once (each stages its own copy of the tables)
                 f.par_spread = (act / 64u * lpc <= 1024u && (uint64_t)(act / 64u) * lpc <= 256ull * (kLdsBudget / par_rec_off)) ? 1u : 0u;
+                ahead_buf = -1; // (this plan goes into the first buffer)
                 hip_check(launch_scan_plan_wide(f, (int)lpc, stream), "k_scan_plan_wide launch");
                 if (o.fast_form == 10 && fast_slots <= 4 && !par_tabg) { f.par_spread = 0; hip_check(launch_sweep_wide_dense(f, act / 64u, par_rec_off, stream), "k_sweep_wide (dense) launch"); }
                 else
@@ -1044,12 +1071,53 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 step += n; left -= n; launches_last++;
                 continue;
             }
-            hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
+            // k_sweep_par4 outside logged windows: plan-ahead (see the members' comment)
+            static const bool ahead_on = [] { const char *e = getenv("GR_DEV_PLAN_AHEAD"); return !e || atoi(e) != 0; }(); // (measurements only: 0 = off)
+            const bool ahead = ahead_on && par && !cur_log && !cur_limit && !sys;
+            if (!ahead) {
+                ahead_buf = -1;
+                hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
+            } else {
+                if (!pstream) {
+                    hip_check(hipStreamCreateWithFlags(&pstream, hipStreamNonBlocking), "hipStreamCreate");
+                    hip_check(hipEventCreateWithFlags(&ev_plan, hipEventDisableTiming), "hipEventCreate");
+                    hip_check(hipEventCreateWithFlags(&ev_pre, hipEventDisableTiming), "hipEventCreate");
+                }
+                d_plan_b.alloc((size_t)(o.n_chains / 64u) * plan_steps + 64);
+                uint32_t *const bufs[2] = {d_plan.p, d_plan_b.p};
+                int rb = 0; // the buffer this launch reads
+                if (ahead_buf >= 0 && ahead_step0 == step && ahead_n >= n && ahead_act == act) {
+                    rb = ahead_buf; // computed ahead (a plan of more steps starts with the plan of fewer)
+                    if (ahead_inflight) { hip_check(hipStreamWaitEvent(stream, ev_plan, 0), "hipStreamWaitEvent"); ahead_inflight = false; }
+                } else {
+                    f.plan = bufs[0];
+                    hip_check(launch_scan_plan(f, stream), "k_scan_plan launch");
+                }
+                f.plan = bufs[rb];
+                // the next launch: the rest of this call, else a repeat of this call's first launch
+                if (first_n == 0) first_n = n;
+                const uint64_t rest = left - n;
+                const uint32_t nn = rest >= gran ? (uint32_t)std::min<uint64_t>(rest - rest % gran, plan_steps) : first_n;
+                hip_check(hipEventRecord(ev_pre, stream), "hipEventRecord"); // (every earlier reader of the other buffer is before this point)
+                hip_check(hipStreamWaitEvent(pstream, ev_pre, 0), "hipStreamWaitEvent");
+                FastParams fn = f;
+                const uint64_t s1 = step + n;
+                fn.plan = bufs[1 - rb]; fn.step0_lo = (uint32_t)s1; fn.step0_hi = (uint32_t)(s1 >> 32); fn.n_steps = nn;
+                ahead_buf = 1 - rb; ahead_step0 = s1; ahead_n = nn; ahead_act = act;
+                // (launched below, right after the sweep, so that the sweep's blocks are resident first)
+                plan_ahead = fn; plan_ahead_pending = true;
+            }
             if (par) {
                 // (measurements only) GR_DEV_BLOCK_TIMES=<file>: start / end time (100 MHz), HW_ID and XCC_ID of every block of the last k_sweep_par4 launch
                 const char *bt = getenv("GR_DEV_BLOCK_TIMES");
                 if (bt) { d_dbg.alloc((size_t)(act / 64u) * 4u); f.dbg_times = d_dbg.p; }
                 hip_check(launch_sweep_par4(f, fast_slots, par_packed, act / 64u, par_lds, stream), "k_sweep_par4 launch");
+                if (plan_ahead_pending) {
+                    plan_ahead_pending = false;
+                    hip_check(launch_scan_plan(plan_ahead, pstream), "k_scan_plan (ahead) launch");
+                    hip_check(hipEventRecord(ev_plan, pstream), "hipEventRecord");
+                    ahead_inflight = true;
+                }
                 if (bt) {
                     std::vector<unsigned long long> t((size_t)(act / 64u) * 4u);
                     download(t.data(), d_dbg.p, t.size() * 8u);

@@ -357,15 +357,18 @@ def test_results_do_not_depend_on_wavefront_priority():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     outs = []
-    for shift in ("32", "0", None):
+    for shift in ("32", "0", None, "no-plan-ahead"):
         env = dict(os.environ)
         env.pop("GR_DEV_PRIO_SHIFT", None)
-        if shift is not None:
+        env.pop("GR_DEV_PLAN_AHEAD", None)
+        if shift == "no-plan-ahead":  # ... nor on whether the next launch's scan plan is computed beside the running sweep (sampler.cpp: plan-ahead)
+            env["GR_DEV_PLAN_AHEAD"] = "0"
+        elif shift is not None:
             env["GR_DEV_PRIO_SHIFT"] = shift
         r = subprocess.run([sys.executable, os.path.join(root, "scripts", "prio_hash.py")], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
         outs.append(r.stdout)
-    assert outs[0] == outs[1] == outs[2] and len(outs[0].strip().splitlines()) == 10
+    assert outs[0] == outs[1] == outs[2] == outs[3] and len(outs[0].strip().splitlines()) == 11
     assert {int(line.split()[4]) for line in outs[0].strip().splitlines()} >= {0, 2, 3, 5, 6, 8, 9}
 
 
