@@ -211,7 +211,7 @@ def roofline(kernel_rate, wall_rate, per_launch_updates, per_launch_s):
                          "bytes are never streamed (north_star's '>= 40 % of HBM roofline' is met in this effective sense only)"}
     out = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G VALU-port cycles/s", "frac": None, "traffic": None,
            "effective_hbm": effective,
-           "launch": {"updates": per_launch_updates, "ms": per_launch_s * 1e3, "note": "mean over the timed steps' launches: k_scan_plan + k_sweep_par4, HIP events on the sampler's stream"}}
+           "launch": {"updates": per_launch_updates, "ms": per_launch_s * 1e3, "note": "mean over the timed steps' launches, HIP events on the sampler's stream: k_sweep_par4 (+ its k_scan_plan when that was not computed ahead, beside the previous sweep, on the sampler's second stream)"}}
     if not os.path.exists(ROOFLINE_INPUTS):
         out["note"] = "profiles/roofline_inputs.json missing: run scripts/collect_profiles.sh + scripts/store_profiles.py on the GPU box"
         return out
