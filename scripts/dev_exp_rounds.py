@@ -1,9 +1,12 @@
+"""Per-round kernel time of the adaptive experiment (Segmentation_11, 2 -> 128 groups of 256 chains, AdvanceChain(2000) + Adapt(+4)): a round costs
+what ONE 64-chain group costs to walk its ~500 000 steps, whatever the number of groups.  argv[1]: fast_form (0 auto, 3 never wide, 8 / 9 = 8 / 16 lanes)."""
 import os, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
 import grample_amd as g
 m = g.Model.NewModelFromFile(os.path.join(ROOT, "tests/golden/res/Segmentation_11.uai"), True)
-s = g.HIPChains(m, 128 * 256, n_variants=128, seed=42)
+form = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+s = g.HIPChains(m, 128 * 256, n_variants=128, seed=42, fast_form=form)
 s.set_active_groups(2); s.BurnIn(2000)
 tot = 0
 for r in range(34):
