@@ -213,7 +213,13 @@ struct gr_sampler {
         if (o.fast_form == 0 && groups * 8u <= 4096u) return 8;
         return 4;
     }
-    bool sys_wide() const { return sysscan && !chroma && fast && par && wide_ok && !no_wide && !strict_fast && (o.fast_form == 0 || o.fast_form == 8 || o.fast_form == 9); } // the systematic scan on k_sweep_wide
+    bool sys_wide_ok() const { return sysscan && fast && par && wide_ok && !no_wide && !strict_fast && (o.fast_form == 0 || o.fast_form == 8 || o.fast_form == 9); } // the systematic scan on k_sweep_wide
+    // The chromatic kernel for this launch?  With the lane slots' records in registers (Grids: 1.3e12) always; with the records staged in
+    // LDS (k_sweep_chroma_l: Segmentation_11, collapsed groups -- one fat block per CU) only while the launch is short of wavefronts:
+    // one wavefront per chain beats every other form up to ~8 192 chains (an adaptive run's first rounds: 6 ms instead of 27), beyond that
+    // the 8-lane form on the sweep order is the faster one (Segmentation_11 collapsed, 32 768 chains: 3.9e11 against 1.6e11)
+    bool use_chroma(uint32_t act) const { return sysscan && chroma && (chroma_rec_off == 0 || act <= 8192u || !sys_wide_ok()); }
+    bool sys_wide() const { return sys_wide_ok() && !use_chroma(active_chains()); }
     bool dir4_chain = false;          // ... with chained factor entries (a factor of arity > 4 or with strides past 16 bits: collapse factors)
     // factor entries of variable v's list in the form this sampler uses: one per factor, or one per pair of other scope variables
     uint32_t dir4_entries(const VariantImage &im, uint32_t v) const {
@@ -316,9 +322,9 @@ void gr_sampler::configure() {
                   (o.fast_form == 0 || o.fast_form == 2 || o.fast_form >= 6) && par_rec_off <= kLdsBudget;
         // (fast_form 10: experiment, see launch_sweep_wide_dense)
     }
-    // systematic scan: the chromatic kernel when every group is binary + memoised with at most 4 lane slots (colour classes cut
-    // into chunks of 64 variables) and 8 neighbours, all groups sweep the same number of variables, and the threshold pool fits
-    // LDS next to the chains' rows; otherwise (and for the sweeps' heads and tails) the generic kernel's systematic mode
+    // systematic scan: the chromatic kernel when every group is binary + memoised with at most 8 lane slots (colour classes cut
+    // into chunks of 64 variables) and 12 neighbours and the threshold pool fits LDS next to the chains' rows (groups may sweep
+    // different numbers of variables: the kernel takes any range of steps); otherwise see run()
     chroma = false;
     if (sysscan) {
         if (stg) throw Error(GR_E_UNSUPPORTED, "GR_FLAG_SCAN_SYSTEMATIC needs the chain state in LDS (model too large, or GR_FLAG_STATE_GLOBAL)");
@@ -331,7 +337,7 @@ void gr_sampler::configure() {
             for (size_t c = 0; c + 1 < im.color_off.size(); ++c) ns += (im.color_off[c + 1] - im.color_off[c] + 63u) / 64u;
             nslot = std::max(nslot, ns);
             cpt_max = std::max<uint32_t>(cpt_max, (im.cpt_words + 3u) & ~3u);
-            ok = ok && im.free_vars.size() == sys_n_free;
+            sys_n_free = std::max<uint32_t>(sys_n_free, (uint32_t)im.free_vars.size()); // (the longest sweep: sizes the block histogram)
             if (ok)
                 for (uint32_t v : im.free_vars) {
                     const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
@@ -1137,10 +1143,10 @@ void gr_sampler::run(uint64_t updates, bool counting) {
     if (cur_log_pc && !strict_fast) {
         generic_small(updates); // strict mode's logged windows on the direct path: the generic kernel's per-chain scan with the per-chain log
     } else if (sysscan) {
-        // systematic scan: whole sweeps from a sweep boundary on the chromatic kernel, everything else (and every model that
-        // kernel does not take) on the generic kernel's systematic mode -- same order, same draws, same thresholds
+        // systematic scan: the chromatic kernel for the models it takes, the plan-based kernels on the sweep order for the other families,
+        // the generic kernel's systematic mode for what is left (and their launch heads / tails) -- same order, same draws, same thresholds
         uint64_t left = updates;
-        if (chroma) {
+        if (use_chroma(act)) {
             FastParams f{};
             f.prio_shift = prio_shift(3); // (a trip of the chromatic kernels' loop is 4 sweeps)
             f.variants = d_variants.p; f.free_vars = d_free.p; f.cprogs = d_cprogs.p; f.cprog_off = d_cprog_off.p; f.cpt = d_cpt.p;
@@ -1150,11 +1156,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi; f.counting = p.counting;
             f.chroma_slots = d_chroma_slots.p; f.recs_chroma = d_recs_chroma.p; f.sys_pos = d_sys_pos.p;
             f.chroma_row = chroma_row; f.chroma_tab_off = chroma_tab_off; f.chroma_wpb = chroma_wpb; f.chroma_hist_off = chroma_hist_off; f.chroma_rec_off = chroma_rec_off;
-            const uint64_t head = std::min<uint64_t>(left, (sys_n_free - step % sys_n_free) % sys_n_free);
-            if (head) { sys_generic(head); left -= head; }
-            while (left >= sys_n_free) {
-                const uint64_t max_sweeps = std::max<uint64_t>(1, kMaxStepsPerLaunch / sys_n_free);
-                const uint32_t n = (uint32_t)(std::min<uint64_t>(left / sys_n_free, max_sweeps) * sys_n_free);
+            while (left) { // any range of steps: the kernel's first and last sweep may be partial (per chain group: collapsed groups sweep fewer variables)
+                const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
                 f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
                 f.n_steps = n;
                 hip_check(launch_sweep_chroma(f, (int)chroma_nslot, fast_slots, act / chroma_wpb, chroma_lds, stream), "k_sweep_chroma launch");
@@ -1846,10 +1849,9 @@ GR_VISIBLE int gr_set_active_groups(gr_sampler *s, uint32_t n_active) {
 }
 GR_VISIBLE int gr_active_groups(gr_sampler *s) { return s ? (int)s->n_active : fail(GR_E_INVALID, "null sampler"); }
 
-GR_VISIBLE int gr_advance_window(gr_sampler *s, uint64_t updates_per_chain) {
-    return guarded([&] {
-        if (!s) throw Error(GR_E_INVALID, "null sampler");
-        if (updates_per_chain < 2) throw Error(GR_E_INVALID, "a convergence window needs at least 2 updates");
+// the two halves of a window of `updates_per_chain` counted updates, in time: counts at the start, in the middle, at the end
+static void window_in_time(gr_sampler *s, uint64_t updates_per_chain) {
+    {
         const size_t n = (size_t)s->o.n_variants * s->H;
         std::vector<uint64_t> c0(n), c1(n), c2(n);
         if (gr_counts(s, c0.data(), nullptr)) throw Error(GR_E_NO_DEVICE, g_err);
@@ -1870,6 +1872,14 @@ GR_VISIBLE int gr_advance_window(gr_sampler *s, uint64_t updates_per_chain) {
         }
         // ConvergenceWindow ~ samples of one variable in one chain of the window
         s->win_cw = std::max(2.0, (double)updates_per_chain / (double)std::max<size_t>(1, s->image[0].free_vars.size()));
+    }
+}
+
+GR_VISIBLE int gr_advance_window(gr_sampler *s, uint64_t updates_per_chain) {
+    return guarded([&] {
+        if (!s) throw Error(GR_E_INVALID, "null sampler");
+        if (updates_per_chain < 2) throw Error(GR_E_INVALID, "a convergence window needs at least 2 updates");
+        window_in_time(s, updates_per_chain);
     });
 }
 
@@ -1878,9 +1888,26 @@ GR_VISIBLE int gr_advance_chain(gr_sampler *s, uint32_t cw, uint64_t *out_update
     return guarded([&] {
         if (!s) throw Error(GR_E_INVALID, "null sampler");
         if (cw < 2) throw Error(GR_E_INVALID, "ConvergenceWindow must be >= 2");
-        if (s->o.flags & GR_FLAG_SCAN_SYSTEMATIC) throw Error(GR_E_UNSUPPORTED, "gr_advance_chain is the random scan's stopping rule (chain.go:184-215): use gr_advance_window with GR_FLAG_SCAN_SYSTEMATIC");
         s->use();
         if (s->dirty) s->rebuild();
+        if (s->o.flags & GR_FLAG_SCAN_SYSTEMATIC) {
+            // AdvanceChain under the systematic scan needs no stopping-time replay and no draw log: a sweep selects every variable once.
+            // cw + 1 sweeps of the longest order among the live groups -- chain.go:184-215's criterion (cw + 1 new samples of every
+            // variable), met exactly by the groups that sweep n_max variables, passed by a selection or so per n_max / (n_max - n_g)
+            // sweeps by a group with fewer (collapsed) ones -- and ChainHistory's halves (circular.go:16-28: the last 2 * (cw / 2)
+            // selections of a variable, oldest half / newest half) are the last 2 * (cw / 2) sweeps split in time: any stretch of
+            // h * n_max updates holds exactly h selections of every variable of an n_max-variable group, wherever it starts.
+            uint64_t n_max = 1;
+            for (uint32_t g = 0; g < (s->o.n_variants > 1 ? s->n_active : 1u); ++g) n_max = std::max<uint64_t>(n_max, s->image[g].free_vars.size());
+            const uint64_t h = cw / 2u, L = (uint64_t)(cw + 1u) * n_max, W = 2ull * h * n_max;
+            double ms = 0; uint32_t nl = 0;
+            if (L > W) { s->run(L - W, true); ms = s->kernel_ms_last; nl = s->launches_last; }
+            window_in_time(s, W);
+            s->kernel_ms_last += ms; s->launches_last += nl;
+            s->win_cw = (double)cw;
+            if (out_updates) *out_updates = L;
+            return;
+        }
         const uint32_t act = s->active_chains();
         if (s->o.flags & GR_FLAG_SCAN_PER_CHAIN) {
             // Strict mode: every chain has its own scan stream, so AdvanceChain is the reference's, chain by chain (chain.go:184-215):
@@ -2275,9 +2302,9 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         if (!s || !out || out->struct_size != sizeof(gr_sampler_info)) throw Error(GR_E_INVALID, "bad gr_sampler_info");
         if (s->dirty) { s->use(); s->configure(); }
         out->block_threads = s->T; out->n_blocks = s->blocks;
-        out->lds_bytes = s->sysscan && s->chroma ? s->chroma_lds : s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->dir4 ? s->dir_lds : s->lds; // of the kernel that actually runs
+        out->lds_bytes = s->use_chroma(s->active_chains()) ? s->chroma_lds : s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->dir4 ? s->dir_lds : s->lds; // of the kernel that actually runs
         if (s->fast && s->par) { out->block_threads = s->strict_fast ? s->T : 64u * s->lpc_last; out->n_blocks = s->active_chains() / 64u; } // (64 x lanes per chain of the last launch)
-        out->path = s->sysscan ? (s->chroma ? 9u : s->pw4 ? 6u : (s->dir4 && !s->fast) ? 8u : s->sys_wide() ? 3u : 0u) : s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
+        out->path = s->sysscan ? (s->use_chroma(s->active_chains()) ? 9u : s->pw4 ? 6u : (s->dir4 && !s->fast) ? 8u : s->sys_wide() ? 3u : 0u) : s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

@@ -66,8 +66,11 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
     const uint32_t tab = lds_addr_c(lds) + p.chroma_tab_off;
     const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
     const uint64_t step0 = ((uint64_t)p.step0_hi << 32) | p.step0_lo;
-    const uint64_t sweep0 = step0 / vd.n_free;                           // (the host launches whole sweeps from a sweep boundary)
-    const uint32_t n_sweeps = p.n_steps / vd.n_free;
+    // any range of steps: the first and the last sweep of the launch may be partial (a lane takes part in them when its position lies
+    // in the range), so that chain groups with different numbers of selectable variables (collapsed groups) share a launch
+    const uint64_t step1 = step0 + p.n_steps;                            // (n_steps >= 1)
+    const uint64_t sw_first = step0 / vd.n_free, sw_last = (step1 - 1u) / vd.n_free;
+    const uint32_t p_lo = (uint32_t)(step0 - sw_first * vd.n_free), p_hi = (uint32_t)(step1 - 1u - sw_last * vd.n_free);
 
     // my variable of every lane slot: loaded once
     bool on[NSLOT];
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
     }
 
     const PrioRotor prio; // (wave_prio.h)
-    for (uint64_t sq = sweep0 >> 2; (sq << 2) < sweep0 + n_sweeps; ++sq) {
+    for (uint64_t sq = sw_first >> 2; (sq << 2) <= sw_last; ++sq) {
         prio.tick((uint32_t)sq, p.prio_shift);
         uint32_t U[NSLOT][4];
 #pragma unroll
@@ -103,10 +106,14 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint64_t sweep = (sq << 2) + (uint64_t)w;
-            if (sweep < sweep0 || sweep >= sweep0 + n_sweeps) continue; // (uniform)
+            if (sweep < sw_first || sweep > sw_last) continue; // (uniform)
+            const bool at_first = sweep == sw_first, at_last = sweep == sw_last; // (uniform)
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 if ((uint32_t)s >= vd.csl_n) break; // (uniform)
+                bool act = on[s];
+                if (at_first) act = act && pos[s] >= p_lo;
+                if (at_last) act = act && pos[s] <= p_hi;
                 // the class before this one has committed: in-order LDS in hardware, the fence for the compiler
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 uint32_t x[SLOTS];
@@ -117,7 +124,7 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
                 for (int i = SLOTS - 1; i >= 0; --i) a = mad_u16_hi_c(mw[s][i], x[i], a);
                 const uint32_t T = *(lds_u32c_t *)(uintptr_t)a;
                 const bool val = U[s][w] >= T;
-                if (on[s]) {
+                if (act) {
                     *(lds_u8c_t *)(uintptr_t)own[s] = val ? (unsigned char)1 : (unsigned char)0;
                     if constexpr (COUNT) ones[s] += val ? 1u : 0u;
                 }
@@ -142,8 +149,11 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s)
             if (on[s] && (uint32_t)s < vd.csl_n) {
+                // updates of my variable in this launch: one per sweep, minus the partial first / last sweep when my position is outside
+                const uint32_t done = sw_first == sw_last ? ((pos[s] >= p_lo && pos[s] <= p_hi) ? 1u : 0u)
+                                                          : (uint32_t)(sw_last - sw_first + 1u) - (pos[s] < p_lo ? 1u : 0u) - (pos[s] > p_hi ? 1u : 0u);
                 atomicAdd(&h[2u * rk[s] + 1u], ones[s]);
-                atomicAdd(&h[2u * rk[s]], n_sweeps - ones[s]);
+                atomicAdd(&h[2u * rk[s]], done - ones[s]);
             }
         __syncthreads();
         unsigned long long *gc = p.counts + (size_t)variant * p.H;
@@ -197,8 +207,9 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
     const uint32_t recs = lds_addr_c(lds) + p.chroma_rec_off + lane * RB;
     const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
     const uint64_t step0 = ((uint64_t)p.step0_hi << 32) | p.step0_lo;
-    const uint64_t sweep0 = step0 / vd.n_free;
-    const uint32_t n_sweeps = p.n_steps / vd.n_free;
+    const uint64_t step1 = step0 + p.n_steps; // any range of steps: partial first / last sweep (see k_sweep_chroma)
+    const uint64_t sw_first = step0 / vd.n_free, sw_last = (step1 - 1u) / vd.n_free;
+    const uint32_t p_lo = (uint32_t)(step0 - sw_first * vd.n_free), p_hi = (uint32_t)(step1 - 1u - sw_last * vd.n_free);
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4u lds_u4_t;
     uint32_t ones[NSLOT], posr[NSLOT];
@@ -208,7 +219,7 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
         posr[s] = (uint32_t)s < vd.csl_n ? ((lds_u4_t *)(uintptr_t)(recs + (uint32_t)s * 64u * RB))->w : 0u;
     }
     const PrioRotor prio; // (wave_prio.h)
-    for (uint64_t sq = sweep0 >> 2; (sq << 2) < sweep0 + n_sweeps; ++sq) {
+    for (uint64_t sq = sw_first >> 2; (sq << 2) <= sw_last; ++sq) {
         prio.tick((uint32_t)sq, p.prio_shift);
         uint32_t U[NSLOT][4];
 #pragma unroll
@@ -220,7 +231,8 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint64_t sweep = (sq << 2) + (uint64_t)w;
-            if (sweep < sweep0 || sweep >= sweep0 + n_sweeps) continue;
+            if (sweep < sw_first || sweep > sw_last) continue;
+            const bool at_first = sweep == sw_first, at_last = sweep == sw_last; // (uniform)
 #pragma unroll
             for (int s = 0; s < (int)NSLOT; ++s) {
                 if ((uint32_t)s >= vd.csl_n) break;
@@ -244,7 +256,10 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
                 }
                 const uint32_t T = *(lds_u32c_t *)(uintptr_t)a;
                 const bool val = U[s][w] >= T;
-                if (h.y != 0xffffffffu) {
+                bool act = h.y != 0xffffffffu;
+                if (at_first) act = act && posr[s] >= p_lo;
+                if (at_last) act = act && posr[s] <= p_hi;
+                if (act) {
                     *(lds_u8c_t *)(uintptr_t)(row + h.x) = val ? (unsigned char)1 : (unsigned char)0;
                     if constexpr (COUNT) ones[s] += val ? 1u : 0u;
                 }
@@ -268,8 +283,10 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
             if ((uint32_t)s >= vd.csl_n) break;
             const uint32_t k = ((lds_u4_t *)(uintptr_t)(recs + (uint32_t)s * 64u * RB))->y;
             if (k != 0xffffffffu) {
+                const uint32_t done = sw_first == sw_last ? ((posr[s] >= p_lo && posr[s] <= p_hi) ? 1u : 0u)
+                                                          : (uint32_t)(sw_last - sw_first + 1u) - (posr[s] < p_lo ? 1u : 0u) - (posr[s] > p_hi ? 1u : 0u);
                 atomicAdd(&hh[2u * k + 1u], ones[s]);
-                atomicAdd(&hh[2u * k], n_sweeps - ones[s]);
+                atomicAdd(&hh[2u * k], done - ones[s]);
             }
         }
         __syncthreads();

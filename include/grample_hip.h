@@ -124,8 +124,10 @@ int gr_error_suite(int32_t n_vars, const int32_t *card, const int32_t *fixed1, c
                                             variable of a colour class, all of a class updated side by side -- full occupancy from 4 096 chains up.
                                             The other model families keep their random-scan kernels (paths 6, 8 and the 8 / 16-lane form of path 3) with
                                             the plan following the sweep order; the generic kernel (path 0) serves what is left.
-                                            Not combinable with GR_FLAG_SCAN_PER_CHAIN; gr_advance_chain / gr_advance_window keep working through
-                                            gr_advance_window only (the stopping rule of AdvanceChain is a property of the random scan). */
+                                            Not combinable with GR_FLAG_SCAN_PER_CHAIN.  gr_advance_chain(cw) runs cw + 1 sweeps of the longest
+                                            order among the live groups (every variable gets its cw + 1 new samples) and takes the ring halves
+                                            from the last 2 * (cw / 2) sweeps split in time (exactly cw / 2 selections of every variable per half
+                                            for the groups that sweep that many variables); gr_advance_window and gr_adapt work as ever. */
 
 typedef struct gr_sampler_opts {
     uint32_t struct_size;    /* = sizeof(gr_sampler_opts) */

@@ -158,7 +158,7 @@ def test_plan_based_kernels_equal_generic_systematic(res_dir, name, ev, chains, 
     assert int(out[0][1].sum()) == chains * (5 * n + 73)
 
 
-@pytest.mark.parametrize("name,path", [("CSP_13.uai", 8), ("Alchemy_11.uai", 8), ("Promedus_14.uai", 3), ("Segmentation_11.uai", 3)])
+@pytest.mark.parametrize("name,path", [("CSP_13.uai", 8), ("Alchemy_11.uai", 8), ("Promedus_14.uai", 3), ("Segmentation_11.uai", 9)])  # (9: the chromatic kernel takes groups of different sweep lengths)
 def test_systematic_plan_kernels_with_collapsed_groups(res_dir, name, path):
     """Systematic scan + collapsed chain groups (each group its own order: the collapsed variable leaves it, the COLLAPSE factor
     re-colours its neighbours; groups of different sweep lengths in one launch): k_sweep_dir4 with chained entries and
@@ -188,7 +188,7 @@ def test_systematic_plan_kernels_with_collapsed_groups(res_dir, name, path):
 
 
 @pytest.mark.parametrize("name,chains,path", [("Grids_13.uai", 65536, 9), ("ObjectDetection_13.uai", 32768, 6), ("CSP_13.uai", 32768, 8),
-                                               ("Promedus_14.uai", 32768, 3), ("Segmentation_11.uai", 32768, 9)])
+                                               ("Promedus_14.uai", 32768, 3), ("Segmentation_11.uai", 32768, 3), ("Segmentation_11.uai", 8192, 9)])  # (Segmentation_11: records in LDS -- chromatic kernel up to 8 192 chains, the 8-lane form beyond)
 def test_systematic_full_size_properties(res_dir, name, chains, path):
     """The systematic scan at the BASELINE sizes, size-independent properties: conservation, every selectable variable updated
     once per sweep, determinism, independence of the launch chunking (launches that start and end inside a sweep) and of the
@@ -220,13 +220,54 @@ def test_systematic_full_size_properties(res_dir, name, chains, path):
     assert np.array_equal(a.LastSample(h + 5), parts[1].LastSample(5))
 
 
+@pytest.mark.parametrize("name,chains,groups", [("Grids_13.uai", 512, 1), ("Segmentation_11.uai", 1024, 4), ("CSP_13.uai", 512, 2), ("ObjectDetection_13.uai", 256, 1)])
+def test_advance_chain_under_the_systematic_scan(res_dir, name, chains, groups):
+    """gr_advance_chain with GR_FLAG_SCAN_SYSTEMATIC: cw + 1 sweeps of the longest order (every variable gets its cw + 1 new samples,
+    chain.go:184-215), ring halves = the last 2 * (cw / 2) sweeps split in time -- exactly cw / 2 selections of every variable per chain
+    in each half for the groups that sweep n_max variables (circular.go:16-28), and gr_adapt works on them."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name))
+    s = g.HIPChains(m, chains, n_variants=groups, seed=3, flags=SYS)
+    cv = [s.Collapse(k, -1)[0] for k in range(1, groups)]
+    s.BurnIn(17)
+    cw = 21
+    c0 = s.counts().copy()
+    L = s.AdvanceChain(cw)
+    n_max = m.n_vars  # group 0 keeps the base model
+    assert L == (cw + 1) * n_max
+    c1 = s.counts()
+    assert int((c1 - c0).sum()) == chains * L
+    a, b, w = s.window_halves()
+    assert w == cw
+    cards = m.cards()
+    hoff = np.concatenate([[0], np.cumsum(cards)])
+    cpv = chains // groups
+    h = cw // 2
+    for v in range(m.n_vars):  # group 0: exactly h selections of every variable per chain and half
+        assert a[0][hoff[v]:hoff[v + 1]].sum() == cpv * h and b[0][hoff[v]:hoff[v + 1]].sum() == cpv * h
+    for k in range(1, groups):  # a group with a collapsed variable sweeps n_max - 1 variables: h or h + 1 selections per half, none of the collapsed one
+        for v in range(m.n_vars):
+            tot = a[k][hoff[v]:hoff[v + 1]].sum()
+            assert (tot == 0) if v == cv[k - 1] else (cpv * h <= tot <= cpv * (h + 1))
+    assert np.all((a + b) <= (c1 - c0))  # the halves are part of the window's counts
+    s.close()
+    if groups > 1:  # the adaptive flow on these windows: 2 live groups, Adapt adds collapsed ones, the next window covers them
+        t = g.HIPChains(m, 6 * 128, n_variants=6, seed=3, flags=SYS)
+        t.set_active_groups(2); t.BurnIn(50)
+        t.AdvanceChain(cw)
+        added, conv = t.Adapt(3)
+        assert len(added) == 3 and t.active_groups() == 5 and np.isfinite(conv[[v for v in range(m.n_vars) if v not in added]]).any()
+        L2 = t.AdvanceChain(cw)
+        assert L2 == (cw + 1) * m.n_vars
+        merged, coll = g.MergeChains([t])
+        assert int(np.sum(coll)) == len(set(added))
+        t.close()
+
+
 def test_systematic_flag_rules(res_dir):
     m = g.Model.NewModelFromFile(os.path.join(res_dir, "Grids_11.uai"))
     with pytest.raises(g.GrError):
         g.HIPChains(m, 64, flags=SYS | g.GR_FLAG_SCAN_PER_CHAIN)
     s = g.HIPChains(m, 256, flags=SYS, seed=1)
-    with pytest.raises(g.GrError):
-        s.AdvanceChain(4)  # the random scan's stopping rule
     s.AdvanceWindow(400)  # the halves of the window in time
     a, b, _ = s.window_halves()
     assert a.sum() + b.sum() == 256 * 400
