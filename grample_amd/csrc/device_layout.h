@@ -129,6 +129,7 @@ struct FastParams {
     const uint32_t *sys_rank;    // the inverse: free-list index of every position of the sweep order.  Non-null = the plan-based
                                  // kernels (k_scan_plan + k_sweep_dir4) run the systematic scan
     uint32_t chroma_row, chroma_tab_off, chroma_wpb, chroma_hist_off;
+    uint32_t chroma_part;        // k_sweep_chroma(_l): 1 = the launch may start / end inside a sweep (per chain group); 0 = whole sweeps from a sweep boundary
     uint32_t chroma_rec_off;     // 0 = the lanes' records live in registers (k_sweep_chroma); else their LDS offset (k_sweep_chroma_l)
     uint32_t par_tab_words;      // k_sweep_par4 with tab_global: the first par_tab_words words of every group's pool are staged in LDS all
                                  // the same (split pool; record word 2 carries bit 31 for a table that stayed in global memory)

@@ -1156,8 +1156,19 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             f.seed_lo = p.seed_lo; f.seed_hi = p.seed_hi; f.counting = p.counting;
             f.chroma_slots = d_chroma_slots.p; f.recs_chroma = d_recs_chroma.p; f.sys_pos = d_sys_pos.p;
             f.chroma_row = chroma_row; f.chroma_tab_off = chroma_tab_off; f.chroma_wpb = chroma_wpb; f.chroma_hist_off = chroma_hist_off; f.chroma_rec_off = chroma_rec_off;
-            while (left) { // any range of steps: the kernel's first and last sweep may be partial (per chain group: collapsed groups sweep fewer variables)
-                const uint32_t n = (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
+            // all live groups sweep the same number of variables: whole sweeps from a sweep boundary on the kernel's plain form (heads and
+            // tails on the generic kernel); else its PART form, which takes any range of steps (the first and last sweep partial, per group)
+            bool same_n = true;
+            for (uint32_t g = 0; g < (o.n_variants > 1 ? n_active : 1u); ++g) same_n = same_n && image[g].free_vars.size() == image[0].free_vars.size();
+            const uint64_t n0 = image[0].free_vars.size();
+            f.chroma_part = same_n ? 0u : 1u;
+            if (same_n) {
+                const uint64_t head = std::min<uint64_t>(left, (n0 - step % n0) % n0);
+                if (head) { sys_generic(head); left -= head; }
+            }
+            while (same_n ? left >= n0 : left > 0) {
+                const uint32_t n = same_n ? (uint32_t)(std::min<uint64_t>(left / n0, std::max<uint64_t>(1, kMaxStepsPerLaunch / n0)) * n0)
+                                          : (uint32_t)std::min<uint64_t>(left, kMaxStepsPerLaunch);
                 f.step0_lo = (uint32_t)step; f.step0_hi = (uint32_t)(step >> 32);
                 f.n_steps = n;
                 hip_check(launch_sweep_chroma(f, (int)chroma_nslot, fast_slots, act / chroma_wpb, chroma_lds, stream), "k_sweep_chroma launch");

@@ -41,7 +41,8 @@ __device__ __forceinline__ uint32_t mad_u16_hi_c(const uint32_t w, const uint32_
 // chroma record (64 bytes per entry of the free list): w0 = the variable's byte inside a chain's row, w1 = its histogram offset
 // (model layout), w2 = byte offset of its threshold table inside the staged pool, w3 = neighbours, w[4 + i] = neighbour's byte
 // inside the row | (4 * multiplier) << 16 (unused slots: the variable's own byte, multiplier 0)
-template <int NSLOT, int SLOTS, bool COUNT>
+// PART: the launch may start and end inside a sweep (see below); without it the host launches whole sweeps from a sweep boundary
+template <int NSLOT, int SLOTS, bool COUNT, bool PART = false>
 __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, nthr = blockDim.x;
@@ -66,11 +67,18 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
     const uint32_t tab = lds_addr_c(lds) + p.chroma_tab_off;
     const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
     const uint64_t step0 = ((uint64_t)p.step0_hi << 32) | p.step0_lo;
-    // any range of steps: the first and the last sweep of the launch may be partial (a lane takes part in them when its position lies
-    // in the range), so that chain groups with different numbers of selectable variables (collapsed groups) share a launch
+    // Any range of steps [step0, step1): whole sweeps in the main loop, and -- so that chain groups that sweep different numbers of
+    // variables (collapsed groups) share a launch, and launches need no generic head or tail -- a partial first and / or last sweep
+    // around it, in which a lane takes part when its position lies in the range (the same code, with the range test; at most two
+    // sweeps per launch).  [The range test inside the main loop, or one loop with two copies of its body, cost the kernel a third
+    // of its rate: 1.27e12 -> 8.8e11 on Grids_13.]
     const uint64_t step1 = step0 + p.n_steps;                            // (n_steps >= 1)
     const uint64_t sw_first = step0 / vd.n_free, sw_last = (step1 - 1u) / vd.n_free;
     const uint32_t p_lo = (uint32_t)(step0 - sw_first * vd.n_free), p_hi = (uint32_t)(step1 - 1u - sw_last * vd.n_free);
+    const bool part_first = PART && (p_lo != 0u || (sw_first == sw_last && p_hi != vd.n_free - 1u)); // the first sweep is partial (or the only, partial one)
+    const bool part_last = PART && sw_last != sw_first && p_hi != vd.n_free - 1u;
+    const uint64_t sweep0 = sw_first + (part_first ? 1u : 0u);          // the whole sweeps: [sweep0, sweep0 + n_sweeps)
+    const uint32_t n_sweeps = (uint32_t)(sw_last + 1u - (part_last ? 1u : 0u) - sweep0);
 
     // my variable of every lane slot: loaded once
     bool on[NSLOT];
@@ -94,8 +102,29 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
         }
     }
 
+    // one sweep restricted to the positions [lo, hi]
+    auto partial_sweep = [&](const uint64_t sweep, const uint32_t lo, const uint32_t hi) {
+#pragma unroll
+        for (int s = 0; s < NSLOT; ++s) {
+            if ((uint32_t)s >= vd.csl_n) break; // (uniform)
+            const u32x4 d = philox_sys_draw(sweep, pos[s], gchain, p.seed_lo, p.seed_hi);
+            const uint32_t wq = (uint32_t)sweep & 3u;
+            const uint32_t u = wq == 0 ? d.x : wq == 1 ? d.y : wq == 2 ? d.z : d.w;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t a = tbl[s];
+#pragma unroll
+            for (int i = SLOTS - 1; i >= 0; --i) a = mad_u16_hi_c(mw[s][i], (uint32_t)*(lds_u8c_t *)(uintptr_t)nb[s][i], a);
+            const uint32_t T = *(lds_u32c_t *)(uintptr_t)a;
+            const bool val = u >= T;
+            if (on[s] && pos[s] >= lo && pos[s] <= hi) {
+                *(lds_u8c_t *)(uintptr_t)own[s] = val ? (unsigned char)1 : (unsigned char)0;
+                if constexpr (COUNT) ones[s] += val ? 1u : 0u;
+            }
+        }
+    };
+    if constexpr (PART) if (part_first) partial_sweep(sw_first, p_lo, sw_first == sw_last ? p_hi : vd.n_free - 1u);
     const PrioRotor prio; // (wave_prio.h)
-    for (uint64_t sq = sw_first >> 2; (sq << 2) <= sw_last; ++sq) {
+    for (uint64_t sq = sweep0 >> 2; (sq << 2) < sweep0 + n_sweeps; ++sq) {
         prio.tick((uint32_t)sq, p.prio_shift);
         uint32_t U[NSLOT][4];
 #pragma unroll
@@ -106,14 +135,10 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint64_t sweep = (sq << 2) + (uint64_t)w;
-            if (sweep < sw_first || sweep > sw_last) continue; // (uniform)
-            const bool at_first = sweep == sw_first, at_last = sweep == sw_last; // (uniform)
+            if (sweep < sweep0 || sweep >= sweep0 + n_sweeps) continue; // (uniform)
 #pragma unroll
             for (int s = 0; s < NSLOT; ++s) {
                 if ((uint32_t)s >= vd.csl_n) break; // (uniform)
-                bool act = on[s];
-                if (at_first) act = act && pos[s] >= p_lo;
-                if (at_last) act = act && pos[s] <= p_hi;
                 // the class before this one has committed: in-order LDS in hardware, the fence for the compiler
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 uint32_t x[SLOTS];
@@ -124,13 +149,14 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
                 for (int i = SLOTS - 1; i >= 0; --i) a = mad_u16_hi_c(mw[s][i], x[i], a);
                 const uint32_t T = *(lds_u32c_t *)(uintptr_t)a;
                 const bool val = U[s][w] >= T;
-                if (act) {
+                if (on[s]) {
                     *(lds_u8c_t *)(uintptr_t)own[s] = val ? (unsigned char)1 : (unsigned char)0;
                     if constexpr (COUNT) ones[s] += val ? 1u : 0u;
                 }
             }
         }
     }
+    if constexpr (PART) if (part_last) partial_sweep(sw_last, 0u, p_hi);
     __syncthreads();
     {
         const uint32_t wpb = p.chroma_wpb, chain0 = blockIdx.x * wpb;
@@ -149,9 +175,9 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
 #pragma unroll
         for (int s = 0; s < NSLOT; ++s)
             if (on[s] && (uint32_t)s < vd.csl_n) {
-                // updates of my variable in this launch: one per sweep, minus the partial first / last sweep when my position is outside
-                const uint32_t done = sw_first == sw_last ? ((pos[s] >= p_lo && pos[s] <= p_hi) ? 1u : 0u)
-                                                          : (uint32_t)(sw_last - sw_first + 1u) - (pos[s] < p_lo ? 1u : 0u) - (pos[s] > p_hi ? 1u : 0u);
+                // updates of my variable in this launch: the whole sweeps + the partial ones my position lies in
+                uint32_t done = n_sweeps;
+                if constexpr (PART) done += ((part_first && pos[s] >= p_lo && (sw_first != sw_last || pos[s] <= p_hi)) ? 1u : 0u) + ((part_last && pos[s] <= p_hi) ? 1u : 0u);
                 atomicAdd(&h[2u * rk[s] + 1u], ones[s]);
                 atomicAdd(&h[2u * rk[s]], done - ones[s]);
             }
@@ -170,7 +196,7 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma(const FastParams p) {
 // any model after a collapse): the lane slots' records -- {own byte, rank, table address, position; SLOTS x (neighbour byte |
 // 4 * multiplier << 16)} -- are staged ONCE per block in LDS, [slot][lane], and read back per update (three 16-byte reads at
 // a 48-byte lane stride: conflict-free); only the draws of the current 4 sweeps and the ones counters stay in registers.
-template <int SLOTS, bool COUNT> // SLOTS = 8 or 12 neighbour words per record
+template <int SLOTS, bool COUNT, bool PART = false> // SLOTS = 8 or 12 neighbour words per record; PART: see k_sweep_chroma
 __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
     constexpr uint32_t NSLOT = 8, RB = 16u + 4u * SLOTS;
     extern __shared__ __align__(16) unsigned char lds[];
@@ -207,9 +233,13 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
     const uint32_t recs = lds_addr_c(lds) + p.chroma_rec_off + lane * RB;
     const uint64_t gchain = (((uint64_t)p.chain_offset_hi << 32) | p.chain_offset_lo) + chain;
     const uint64_t step0 = ((uint64_t)p.step0_hi << 32) | p.step0_lo;
-    const uint64_t step1 = step0 + p.n_steps; // any range of steps: partial first / last sweep (see k_sweep_chroma)
+    const uint64_t step1 = step0 + p.n_steps; // any range of steps: partial first / last sweep around the whole ones (see k_sweep_chroma)
     const uint64_t sw_first = step0 / vd.n_free, sw_last = (step1 - 1u) / vd.n_free;
     const uint32_t p_lo = (uint32_t)(step0 - sw_first * vd.n_free), p_hi = (uint32_t)(step1 - 1u - sw_last * vd.n_free);
+    const bool part_first = PART && (p_lo != 0u || (sw_first == sw_last && p_hi != vd.n_free - 1u));
+    const bool part_last = PART && sw_last != sw_first && p_hi != vd.n_free - 1u;
+    const uint64_t sweep0 = sw_first + (part_first ? 1u : 0u);
+    const uint32_t n_sweeps = (uint32_t)(sw_last + 1u - (part_last ? 1u : 0u) - sweep0);
     typedef uint32_t v4u __attribute__((ext_vector_type(4)));
     typedef __attribute__((address_space(3))) v4u lds_u4_t;
     uint32_t ones[NSLOT], posr[NSLOT];
@@ -218,8 +248,33 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
         ones[s] = 0;
         posr[s] = (uint32_t)s < vd.csl_n ? ((lds_u4_t *)(uintptr_t)(recs + (uint32_t)s * 64u * RB))->w : 0u;
     }
+    auto partial_sweep = [&](const uint64_t sweep, const uint32_t lo, const uint32_t hi) { // one sweep restricted to the positions [lo, hi]
+#pragma unroll
+        for (int s = 0; s < (int)NSLOT; ++s) {
+            if ((uint32_t)s >= vd.csl_n) break;
+            const u32x4 d = philox_sys_draw(sweep, posr[s], gchain, p.seed_lo, p.seed_hi);
+            const uint32_t wq = (uint32_t)sweep & 3u;
+            const uint32_t u = wq == 0 ? d.x : wq == 1 ? d.y : wq == 2 ? d.z : d.w;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const uint32_t ra = recs + (uint32_t)s * 64u * RB;
+            const v4u h = *(lds_u4_t *)(uintptr_t)ra;
+            uint32_t a = h.z;
+#pragma unroll
+            for (int i = SLOTS - 1; i >= 0; --i) {
+                const uint32_t wv = *(lds_u32c_t *)(uintptr_t)(ra + 16u + 4u * (uint32_t)i);
+                a = mad_u16_hi_c(wv, (uint32_t)*(lds_u8c_t *)(uintptr_t)(row + (wv & 0xffffu)), a);
+            }
+            const uint32_t T = *(lds_u32c_t *)(uintptr_t)a;
+            const bool val = u >= T;
+            if (h.y != 0xffffffffu && posr[s] >= lo && posr[s] <= hi) {
+                *(lds_u8c_t *)(uintptr_t)(row + h.x) = val ? (unsigned char)1 : (unsigned char)0;
+                if constexpr (COUNT) ones[s] += val ? 1u : 0u;
+            }
+        }
+    };
+    if constexpr (PART) if (part_first) partial_sweep(sw_first, p_lo, sw_first == sw_last ? p_hi : vd.n_free - 1u);
     const PrioRotor prio; // (wave_prio.h)
-    for (uint64_t sq = sw_first >> 2; (sq << 2) <= sw_last; ++sq) {
+    for (uint64_t sq = sweep0 >> 2; (sq << 2) < sweep0 + n_sweeps; ++sq) {
         prio.tick((uint32_t)sq, p.prio_shift);
         uint32_t U[NSLOT][4];
 #pragma unroll
@@ -231,8 +286,7 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const uint64_t sweep = (sq << 2) + (uint64_t)w;
-            if (sweep < sw_first || sweep > sw_last) continue;
-            const bool at_first = sweep == sw_first, at_last = sweep == sw_last; // (uniform)
+            if (sweep < sweep0 || sweep >= sweep0 + n_sweeps) continue;
 #pragma unroll
             for (int s = 0; s < (int)NSLOT; ++s) {
                 if ((uint32_t)s >= vd.csl_n) break;
@@ -256,16 +310,14 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
                 }
                 const uint32_t T = *(lds_u32c_t *)(uintptr_t)a;
                 const bool val = U[s][w] >= T;
-                bool act = h.y != 0xffffffffu;
-                if (at_first) act = act && posr[s] >= p_lo;
-                if (at_last) act = act && posr[s] <= p_hi;
-                if (act) {
+                if (h.y != 0xffffffffu) {
                     *(lds_u8c_t *)(uintptr_t)(row + h.x) = val ? (unsigned char)1 : (unsigned char)0;
                     if constexpr (COUNT) ones[s] += val ? 1u : 0u;
                 }
             }
         }
     }
+    if constexpr (PART) if (part_last) partial_sweep(sw_last, 0u, p_hi);
     __syncthreads();
     {
         const uint32_t wpb = p.chroma_wpb, chain0 = blockIdx.x * wpb;
@@ -283,8 +335,8 @@ __global__ void __launch_bounds__(1024) k_sweep_chroma_l(const FastParams p) {
             if ((uint32_t)s >= vd.csl_n) break;
             const uint32_t k = ((lds_u4_t *)(uintptr_t)(recs + (uint32_t)s * 64u * RB))->y;
             if (k != 0xffffffffu) {
-                const uint32_t done = sw_first == sw_last ? ((posr[s] >= p_lo && posr[s] <= p_hi) ? 1u : 0u)
-                                                          : (uint32_t)(sw_last - sw_first + 1u) - (posr[s] < p_lo ? 1u : 0u) - (posr[s] > p_hi ? 1u : 0u);
+                uint32_t done = n_sweeps;
+                if constexpr (PART) done += ((part_first && posr[s] >= p_lo && (sw_first != sw_last || posr[s] <= p_hi)) ? 1u : 0u) + ((part_last && posr[s] <= p_hi) ? 1u : 0u);
                 atomicAdd(&hh[2u * k + 1u], ones[s]);
                 atomicAdd(&hh[2u * k], done - ones[s]);
             }
@@ -308,6 +360,7 @@ static hipError_t launch_chroma_t(const FastParams &p, uint32_t blocks, uint32_t
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64u * p.chroma_wpb), lds, s, p);
         return hipGetLastError();
     };
+    if (p.chroma_part) return p.counting ? go(&k_sweep_chroma<NSLOT, SLOTS, true, true>) : go(&k_sweep_chroma<NSLOT, SLOTS, false, true>);
     return p.counting ? go(&k_sweep_chroma<NSLOT, SLOTS, true>) : go(&k_sweep_chroma<NSLOT, SLOTS, false>);
 }
 
@@ -319,6 +372,7 @@ static hipError_t launch_chroma_l_t(const FastParams &p, uint32_t blocks, uint32
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(64u * p.chroma_wpb), lds, s, p);
         return hipGetLastError();
     };
+    if (p.chroma_part) return p.counting ? go(&k_sweep_chroma_l<SLOTS, true, true>) : go(&k_sweep_chroma_l<SLOTS, false, true>);
     return p.counting ? go(&k_sweep_chroma_l<SLOTS, true>) : go(&k_sweep_chroma_l<SLOTS, false>);
 }
 
