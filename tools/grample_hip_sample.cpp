@@ -39,7 +39,7 @@ int main(int argc, char **argv) {
     long chains = 65536, groups = 0, burnin = -1, maxiters = -1, rounds = 10, seed = 42, cwin = 0, maxsecs = 0, chainadds = -1, adapt_rounds = -1;
     int device = 0;
     bool experiment = false, rounds_given = false;
-    std::string trace_file;
+    std::string trace_file, scan = "random";
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() -> const char * { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return argv[++i]; };
@@ -60,9 +60,10 @@ int main(int argc, char **argv) {
         else if (a == "-w" || a == "--cwin") cwin = std::atol(next());
         else if (a == "-e" || a == "--seed") seed = std::atol(next());
         else if (a == "--device") device = std::atoi(next());
+        else if (a == "--scan") scan = next(); // random (default: one variable per 64-chain group and update) | strict (the reference's: one per chain) | systematic
         else { std::fprintf(stderr, "unknown flag %s\n", a.c_str()); return 2; }
     }
-    if (model.empty()) { std::fprintf(stderr, "usage: %s -m MODEL.uai [-s simple|collapsed] [-o] [-d] [-c chains] ...\n", argv[0]); return 2; }
+    if (model.empty()) { std::fprintf(stderr, "usage: %s -m MODEL.uai [-s simple|collapsed|adaptive] [-o] [-d] [-c chains] [--scan random|strict|systematic] ...\n", argv[0]); return 2; }
     const bool collapsed = samp == "collapsed", adaptive = samp == "adaptive";
     if (!collapsed && !adaptive && samp != "simple") { std::fprintf(stderr, "Unknown Sampler: %s\n", samp.c_str()); return 2; }
     if (experiment && trace_file.empty()) { std::fprintf(stderr, "Experiment mode requires a trace file\n"); return 2; }            // root.go:315-317
@@ -105,6 +106,9 @@ int main(int argc, char **argv) {
     o.n_variants = (uint32_t)groups;
     o.device = device;
     o.seed = (uint64_t)seed;
+    if (scan == "strict") o.flags |= GR_FLAG_SCAN_PER_CHAIN;
+    else if (scan == "systematic") o.flags |= GR_FLAG_SCAN_SYSTEMATIC;
+    else if (scan != "random") { std::fprintf(stderr, "unknown --scan %s (random | strict | systematic)\n", scan.c_str()); return 2; }
     gr_sampler *s = gr_sampler_create(m, &o);
     if (!s) die("Could not create sampler");
     std::printf("Creating %ld chains in %ld group(s) and performing burn-in (%ld)\n", chains, groups, burnin);
