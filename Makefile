@@ -10,7 +10,7 @@ OBJDIR := build/obj
 # way in all three.
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fvisibility=hidden -Wall -Wno-unused-result
 LIB := grample_amd/libgrample_hip.so
-OBJS := $(OBJDIR)/kernels.o $(OBJDIR)/kernels_1.o $(OBJDIR)/kernels_2.o $(OBJDIR)/sweep_bin.o $(OBJDIR)/sweep_par4_1.o $(OBJDIR)/sweep_par4_2.o $(OBJDIR)/sweep_par4_3.o $(OBJDIR)/sweep_par4_4.o $(OBJDIR)/sweep_par4_5.o $(OBJDIR)/sweep_pw4.o $(OBJDIR)/sweep_dir4.o $(OBJDIR)/sweep_chroma.o $(OBJDIR)/sampler.o $(OBJDIR)/host_model.o $(OBJDIR)/compiled_model.o
+OBJS := $(OBJDIR)/kernels.o $(OBJDIR)/kernels_1.o $(OBJDIR)/kernels_2.o $(OBJDIR)/sweep_bin.o $(OBJDIR)/sweep_par4_1.o $(OBJDIR)/sweep_par4_2.o $(OBJDIR)/sweep_par4_3.o $(OBJDIR)/sweep_par4_4.o $(OBJDIR)/sweep_par4_5.o $(OBJDIR)/sweep_pw4.o $(OBJDIR)/sweep_dir4.o $(OBJDIR)/sweep_chroma.o $(OBJDIR)/sweep_bits.o $(OBJDIR)/sampler.o $(OBJDIR)/host_model.o $(OBJDIR)/compiled_model.o
 
 TOOL := tools/grample_hip_sample
 
@@ -45,6 +45,10 @@ $(OBJDIR)/sweep_par4_%.o: $(CSRC)/sweep_bin.hip $(CSRC)/kernels.h $(CSRC)/device
 	$(HIPCC) $(HIPFLAGS) -DGR_PAR4_PART=$* -c $< -o $@
 
 $(OBJDIR)/sweep_chroma.o: $(CSRC)/sweep_chroma.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/wave_prio.h
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OBJDIR)/sweep_bits.o: $(CSRC)/sweep_bits.hip $(CSRC)/kernels.h $(CSRC)/device_layout.h $(CSRC)/philox.h $(CSRC)/wave_prio.h
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

@@ -52,6 +52,7 @@ hipError_t launch_scan_plan(const FastParams &p, hipStream_t s);
 hipError_t launch_sweep_strict(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s);
 hipError_t launch_sweep_bin(const FastParams &p, int slots, uint32_t blocks, uint32_t threads, uint32_t lds, hipStream_t s);
 hipError_t launch_sweep_par4(const FastParams &p, int slots, bool packed, uint32_t blocks, uint32_t lds, hipStream_t s);
+hipError_t launch_sweep_bits(const FastParams &p, int slots, uint32_t blocks, uint32_t lds, hipStream_t s); // 4 lanes per chain, bit-packed state (fast_form 11)
 // wide step-parallel form (8 or 16 lanes per chain; sweep_bin.hip, GR_PAR4_PART 5): its own scan plan + sweep, burn-in / counting only
 hipError_t launch_scan_plan_wide(const FastParams &p, int lpc, hipStream_t s);
 hipError_t launch_sweep_wide(const FastParams &p, int lpc, int slots, uint32_t groups, uint32_t lds, hipStream_t s);

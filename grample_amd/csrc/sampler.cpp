@@ -158,6 +158,9 @@ struct gr_sampler {
     int fast_slots = 0;               // max neighbours of any selectable variable
     uint32_t plan_steps = 0;          // steps per fast launch (plan row length)
     DevBuf<uint32_t> d_recs, d_plan, d_recs_par, d_err;
+    DevBuf<uint32_t> d_recs_bits;     // records of the bit-packed 4-lane form (k_sweep_bits, fast_form 11)
+    bool bits = false;                // ... which this sampler runs (outside logged windows)
+    uint32_t bits_lds = 0;
     bool par_packed = false;          // step-parallel records use one dword per neighbour
     uint32_t rec_stride = 64;         // bytes per record (128 when a variable has 13..16 neighbours)
     bool par = false;                 // step-parallel form (k_sweep_par4): 4 lanes per chain
@@ -737,6 +740,35 @@ void gr_sampler::rebuild() {
             }
             d_recs_par.upload(rp, stream, stage);
         }
+        // fast_form 11: the 4-lane form with bit-packed state (k_sweep_bits) -- binary memoised models with <= 12 neighbours, tables in LDS
+        bits = o.fast_form == 11 && par && !par_tabg && fast_slots <= 12 && (uint64_t)n_vars * 8u < 65536u && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SCAN_SYSTEMATIC));
+        if (o.fast_form == 11 && !bits) throw Error(GR_E_UNSUPPORTED, "fast_form 11 (bit-packed state) needs a binary memoised model with at most 12 neighbours per variable and its tables in LDS");
+        if (bits) {
+            std::vector<uint32_t> rb;
+            uint32_t nfree_max = 1, cpt_max = 4;
+            for (uint32_t g = 0; g < n_build; ++g) {
+                const VariantImage &im = image[g];
+                nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)im.free_vars.size());
+                cpt_max = std::max<uint32_t>(cpt_max, (im.cpt_words + 3u) & ~3u);
+                uint32_t rank = 0;
+                for (uint32_t v : im.free_vars) {
+                    const uint32_t *cp = im.cprog.data() + im.cprog_off[v];
+                    const uint32_t nn = (cp[0] >> 8) & 0xffu;
+                    uint32_t r[16] = {0};
+                    // absolute LDS addresses of the kernel's layout: masks | histogram pairs (by rank) | tables
+                    const uint32_t hist_g = ((uint32_t)n_vars * 8u + 15u) & ~15u, tab_g = (hist_g + (uint32_t)im.free_vars.size() * 8u + 15u) & ~15u;
+                    r[0] = v * 8u; r[1] = hist_g + 8u * rank; r[2] = tab_g + cp[2] * 4u; r[3] = nn;
+                    for (uint32_t i = 0; i < 12u; ++i) r[4 + i] = ((i < nn ? cp[3 + 2 * i] : v) * 8u) | ((i < nn ? cp[4 + 2 * i] * 4u : 0u) << 16);
+                    rb.insert(rb.end(), r, r + 16);
+                    ++rank;
+                }
+            }
+            rb.resize(rb.size() + 16, 0);
+            d_recs_bits.upload(rb, stream, stage);
+            const uint32_t hist_off = ((uint32_t)n_vars * 8u + 15u) & ~15u, tab_off = (hist_off + nfree_max * 8u + 15u) & ~15u;
+            bits_lds = (tab_off + cpt_max * 4u + 15u) & ~15u;
+            if (bits_lds > kLdsBudget) throw Error(GR_E_UNSUPPORTED, "fast_form 11 (bit-packed state): the tables do not fit LDS");
+        }
 
         const uint64_t waves = o.n_chains / 64u;
         uint64_t ps = (256ull << 20) / (waves * 4ull); // <= 256 MiB of plan per launch
@@ -1032,6 +1064,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             if (sys && lpc == 4) lpc = 8; // (the systematic scan exists in the wide forms only: k_sweep_par4 is left as it is)
         }
         if (sys && lpc == 4) throw Error(GR_E_STATE, "systematic scan on the 4-lane form (internal error)");
+        const bool use_bits = bits && par && lpc == 4 && !cur_log && !cur_limit && !sys; // (logged windows keep the byte layout's kernels)
+        if (use_bits) { f.rec_stride = 64; f.recs_par = d_recs_bits.p; }
         if (par) lpc_last = lpc;
         uint32_t first_n = 0;             // plan-ahead: this call's first launch
         FastParams plan_ahead{};          // ... and the plan kernel to launch behind the current sweep
@@ -1117,6 +1151,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
                 // (measurements only) GR_DEV_BLOCK_TIMES=<file>: start / end time (100 MHz), HW_ID and XCC_ID of every block of the last k_sweep_par4 launch
                 const char *bt = getenv("GR_DEV_BLOCK_TIMES");
                 if (bt) { d_dbg.alloc((size_t)(act / 64u) * 4u); f.dbg_times = d_dbg.p; }
+                if (use_bits) hip_check(launch_sweep_bits(f, fast_slots, act / 64u, bits_lds, stream), "k_sweep_bits launch");
+                else
                 hip_check(launch_sweep_par4(f, fast_slots, par_packed, act / 64u, par_lds, stream), "k_sweep_par4 launch");
                 if (plan_ahead_pending) {
                     plan_ahead_pending = false;
@@ -2313,9 +2349,9 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         if (!s || !out || out->struct_size != sizeof(gr_sampler_info)) throw Error(GR_E_INVALID, "bad gr_sampler_info");
         if (s->dirty) { s->use(); s->configure(); }
         out->block_threads = s->T; out->n_blocks = s->blocks;
-        out->lds_bytes = s->use_chroma(s->active_chains()) ? s->chroma_lds : s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->dir4 ? s->dir_lds : s->lds; // of the kernel that actually runs
+        out->lds_bytes = s->use_chroma(s->active_chains()) ? s->chroma_lds : s->bits ? s->bits_lds : s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->dir4 ? s->dir_lds : s->lds; // of the kernel that actually runs
         if (s->fast && s->par) { out->block_threads = s->strict_fast ? s->T : 64u * s->lpc_last; out->n_blocks = s->active_chains() / 64u; } // (64 x lanes per chain of the last launch)
-        out->path = s->sysscan ? (s->use_chroma(s->active_chains()) ? 9u : s->pw4 ? 6u : (s->dir4 && !s->fast) ? 8u : s->sys_wide() ? 3u : 0u) : s->fast ? (s->strict_fast ? 5u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
+        out->path = s->sysscan ? (s->use_chroma(s->active_chains()) ? 9u : s->pw4 ? 6u : (s->dir4 && !s->fast) ? 8u : s->sys_wide() ? 3u : 0u) : s->fast ? (s->strict_fast ? 5u : s->bits ? 11u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

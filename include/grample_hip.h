@@ -144,7 +144,7 @@ typedef struct gr_sampler_opts {
                                 4, 5, 6 = 4 lanes per chain with the step records read from LDS one by one / from LDS together /
                                 from global memory one iteration ahead (2 picks by occupancy); 7 = as 6 with the threshold pool split
                                 between LDS (its first half) and global memory whatever the occupancy (cross-checks of that kernel);
-                                3 = as 0, but never more than 4 lanes per chain (measurements); 8, 9 = 8 / 16 lanes per chain (binary memoised models; chosen automatically while a launch has too few
+                                3 = as 0, but never more than 4 lanes per chain (measurements); 11 = 4 lanes per chain with bit-packed state (one 16-bit mask per variable and wavefront; binary memoised models, <= 12 neighbours, tables in LDS; GR_E_UNSUPPORTED otherwise); 8, 9 = 8 / 16 lanes per chain (binary memoised models; chosen automatically while a launch has too few
                                 wavefronts for the chip: small chain counts, the first rounds of an adaptive run, models whose LDS
                                 footprint leaves a CU two 64-chain blocks) */
 } gr_sampler_opts;
@@ -253,6 +253,7 @@ typedef struct gr_sampler_info {
                                6 = direct conditional, value-parallel (4 lanes per chain, pairwise models with 8 < Card <= 16);
                                8 = direct conditional, step-parallel (4 lanes per chain: Card <= 4, blankets too large to memoise; collapse factors as chained entries);
                                9 = systematic (chromatic) scan on memoised tables, one wavefront per chain (GR_FLAG_SCAN_SYSTEMATIC);
+                               11 = as 3 with the chain state bit-packed in LDS (fast_form 11: a measured alternative, never chosen automatically);
                                + 16 when the chain state stays in global memory (paths 0 and 1 only) */
     uint32_t max_card;
     uint32_t tables_in_lds; /* threshold / view tables: 1 = staged in LDS, 0 = read from global memory, 2 = split (4-lane memoised form:

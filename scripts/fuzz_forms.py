@@ -84,7 +84,7 @@ def main():
         forms = {"chain_per_lane": dict(fast_form=1), "direct": dict(flags=g.GR_FLAG_DIRECT), "sequential": dict(flags=g.GR_FLAG_SEQUENTIAL),
                  "state_global": dict(flags=g.GR_FLAG_STATE_GLOBAL), "state_global_direct": dict(flags=g.GR_FLAG_STATE_GLOBAL | g.GR_FLAG_DIRECT),
                  "form2": dict(fast_form=2), "form3_no_wide": dict(fast_form=3), "form6": dict(fast_form=6), "form7_split_pool": dict(fast_form=7),
-                 "form8_wide8": dict(fast_form=8), "form9_wide16": dict(fast_form=9)}
+                 "form8_wide8": dict(fast_form=8), "form9_wide16": dict(fast_form=9), "form11_bit_packed_state": dict(fast_form=11)}
         paths = [ref[0]]
         for name, kw in forms.items():
             try:

@@ -271,13 +271,13 @@ def test_all_kernel_forms_agree_bit_for_bit(res_dir):
     runs = {}
     for path, kw in {0: dict(flags=g.GR_FLAG_DIRECT), 1: dict(block_threads=64), 2: dict(fast_form=1), 3: dict(fast_form=2),
                      34: dict(fast_form=4), 35: dict(fast_form=5), 36: dict(fast_form=6), 37: dict(fast_form=7),
-                     38: dict(fast_form=8), 39: dict(fast_form=9)}.items():
+                     38: dict(fast_form=8), 39: dict(fast_form=9), 41: dict(fast_form=11)}.items():
         s = g.HIPChains(m, 2048, seed=9, chain_offset=64 * 3, **kw)
         s.BurnIn(333); s.Advance(1001); s.Advance(2 * 4096 + 3)
         runs[path] = (s.info()["path"], s.counts(), np.stack([s.LastSample(c) for c in (0, 63, 64, 1000, 2047)]), s.info()["block_threads"])
-    assert [runs[k][0] for k in sorted(runs)] in ([0, 1, 2, 3, 3, 3, 3, 3, 3, 3], [0, 2, 2, 3, 3, 3, 3, 3, 3, 3])
+    assert [runs[k][0] for k in sorted(runs)] in ([0, 1, 2, 3, 3, 3, 3, 3, 3, 3, 11], [0, 2, 2, 3, 3, 3, 3, 3, 3, 3, 11])
     assert [runs[k][3] for k in (36, 38, 39)] == [256, 512, 1024]  # 4, 8 and 16 lanes per chain
-    for k in (1, 2, 3, 34, 35, 36, 37, 38, 39):  # 34..36: the 4-lane form's three record sources; 37: split threshold pool; 38, 39: wide forms
+    for k in (1, 2, 3, 34, 35, 36, 37, 38, 39, 41):  # 34..36: the 4-lane form's three record sources; 37: split threshold pool; 38, 39: wide forms; 41: bit-packed state (k_sweep_bits)
         assert np.array_equal(runs[0][1], runs[k][1]), k
         assert np.array_equal(runs[0][2], runs[k][2]), k
 
@@ -370,6 +370,26 @@ def test_results_do_not_depend_on_wavefront_priority():
         outs.append(r.stdout)
     assert outs[0] == outs[1] == outs[2] == outs[3] and len(outs[0].strip().splitlines()) == 11
     assert {int(line.split()[4]) for line in outs[0].strip().splitlines()} >= {0, 2, 3, 5, 6, 8, 9}
+
+
+@pytest.mark.parametrize("name,ev,chains,groups", [("Grids_13.uai", False, 65536, 1), ("Segmentation_11.uai", False, 4096, 4), ("Promedus_11.uai", True, 1024, 1), ("dv-rel_1.uai", True, 2048, 1)])
+def test_bit_packed_state_form_equals_byte_form(res_dir, name, ev, chains, groups):
+    """fast_form 11 (k_sweep_bits: one 16-bit mask per variable and wavefront instead of one byte per chain; SURVEY 8(f) N4 "bit-packed
+    binary state") is the same process as the byte layout's kernels, bit for bit: counts and states after quad-unaligned launches, with
+    evidence, with collapsed chain groups; logged AdvanceChain windows (which keep the byte layout) interleave freely."""
+    m = g.Model.NewModelFromFile(os.path.join(res_dir, name), ev)
+    out = []
+    for form in (11, 3):
+        s = g.HIPChains(m, chains, n_variants=groups, seed=19, chain_offset=(1 << 33) + 128, fast_form=form)
+        cv = [s.Collapse(k, -1)[0] for k in range(1, groups)]
+        s.BurnIn(77); s.Advance(3 * m.n_vars + 5); s.Advance(64)
+        path = s.info()["path"]
+        L = s.AdvanceChain(10) if chains <= 4096 else 0
+        s.Advance(129)
+        out.append((path, cv, L, s.counts(), s.checkpoint()["states"]))
+        s.close()
+    assert out[0][0] == 11 and out[1][0] == 3 and out[0][1] == out[1][1] and out[0][2] == out[1][2]
+    assert np.array_equal(out[0][3], out[1][3]) and np.array_equal(out[0][4], out[1][4])
 
 
 def test_cross_form_fuzz():
