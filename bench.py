@@ -125,7 +125,7 @@ def oracle_probe(res_dir, g, name, sampler="simple", chains=256, burn_sweeps=20,
 
 PATHS = {0: "direct (k_sweep)", 1: "memoised (k_sweep)", 2: "memoised+plan, chain per lane (k_sweep_bin)", 3: "memoised+plan, step-parallel (k_sweep_par4 / k_sweep_wide)",
          5: "memoised, strict per-chain scan (k_sweep_strict)", 6: "direct, value-parallel (k_sweep_pw4)", 8: "direct, step-parallel (k_sweep_dir4)",
-         9: "memoised, systematic scan, one wavefront per chain (k_sweep_chroma)"}
+         9: "memoised, systematic scan, one wavefront per chain (k_sweep_chroma)", 11: "memoised+plan, step-parallel, bit-packed state (k_sweep_bits)"}
 
 
 def other_configs(res_dir, g, device):

@@ -741,7 +741,23 @@ void gr_sampler::rebuild() {
             d_recs_par.upload(rp, stream, stage);
         }
         // fast_form 11: the 4-lane form with bit-packed state (k_sweep_bits) -- binary memoised models with <= 12 neighbours, tables in LDS
-        bits = o.fast_form == 11 && par && !par_tabg && fast_slots <= 12 && (uint64_t)n_vars * 8u < 65536u && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SCAN_SYSTEMATIC));
+        // Chosen by the sampler itself (fast_form 0) where the STATE is what fills LDS: a model whose byte layout leaves a CU one block
+        // and whose bit layout leaves it two (dv-rel_2: 1 200 variables, 144 KB -> 58 KB, 1.4e11 -> 4.8e11 updates/s); everywhere
+        // else the form costs 13 more VALU instructions per 64 updates than the byte layout and is slower (profiles/r03_bits_form.txt).
+        const bool bits_can = par && !par_tabg && fast_slots <= 12 && (uint64_t)n_vars * 8u < 65536u && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SCAN_SYSTEMATIC));
+        uint32_t bits_need = 0;
+        if (bits_can) {
+            uint32_t nfree_max = 1, cpt_max = 4;
+            for (uint32_t g = 0; g < n_build; ++g) {
+                nfree_max = std::max<uint32_t>(nfree_max, (uint32_t)image[g].free_vars.size());
+                cpt_max = std::max<uint32_t>(cpt_max, (image[g].cpt_words + 3u) & ~3u);
+            }
+            const uint32_t hist_off = ((uint32_t)n_vars * 8u + 15u) & ~15u, tab_off = (hist_off + nfree_max * 8u + 15u) & ~15u;
+            bits_need = (tab_off + cpt_max * 4u + 15u) & ~15u;
+        }
+        // (state-dominated: the chains' bytes alone take more than half of a CU's LDS; models whose TABLES fill LDS keep the byte layout and its wide forms)
+        const bool bits_auto = o.fast_form == 0 && bits_can && !strict_fast && (uint64_t)n_vars * kParStateStride > kLdsBudget / 2u && par_lds > kLdsBudget / 2u && bits_need <= kLdsBudget / 2u;
+        bits = (o.fast_form == 11 || bits_auto) && bits_can;
         if (o.fast_form == 11 && !bits) throw Error(GR_E_UNSUPPORTED, "fast_form 11 (bit-packed state) needs a binary memoised model with at most 12 neighbours per variable and its tables in LDS");
         if (bits) {
             std::vector<uint32_t> rb;

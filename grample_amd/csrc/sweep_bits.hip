@@ -9,7 +9,8 @@
 // Built to MEASURE the form, not to replace the byte layout: the inner loop needs the same number of LDS instructions (a
 // row-uniform u16 read costs the LDS pipe what a per-lane byte read does) and ~10 VALU instructions more per step for the bit
 // extracts and the mask slice (scripts/ubench/state_form.hip: 1.06e12 against 1.26e12 updates/s in isolation); what it saves is
-// LDS footprint, which the headline launch does not lack.  The sampler never picks it by itself.
+// LDS footprint, which the headline launch does not lack.  The sampler picks it by itself for the models whose STATE fills LDS (more than
+// half of a CU's 160 KB as bytes: dv-rel_2, 1 200 variables -- two blocks per CU instead of one, 3.0e11 -> 4.6e11); fast_form 11 forces it.
 //
 // Records (64 bytes per selectable variable, built by gr_sampler::rebuild for this form with absolute LDS addresses -- the dynamic LDS
 // array must start at LDS address 0, checked like in k_sweep_par4 -- and read from global memory one iteration ahead):

@@ -253,7 +253,7 @@ typedef struct gr_sampler_info {
                                6 = direct conditional, value-parallel (4 lanes per chain, pairwise models with 8 < Card <= 16);
                                8 = direct conditional, step-parallel (4 lanes per chain: Card <= 4, blankets too large to memoise; collapse factors as chained entries);
                                9 = systematic (chromatic) scan on memoised tables, one wavefront per chain (GR_FLAG_SCAN_SYSTEMATIC);
-                               11 = as 3 with the chain state bit-packed in LDS (fast_form 11: a measured alternative, never chosen automatically);
+                               11 = as 3 with the chain state bit-packed in LDS (chosen for models whose state bytes would take more than half of a CU's LDS; fast_form 11 forces it);
                                + 16 when the chain state stays in global memory (paths 0 and 1 only) */
     uint32_t max_card;
     uint32_t tables_in_lds; /* threshold / view tables: 1 = staged in LDS, 0 = read from global memory, 2 = split (4-lane memoised form:

@@ -18,7 +18,7 @@ import grample_amd as g  # noqa: E402
 RES = os.path.join(ROOT, "tests", "golden", "res")
 CHAINS = [512, 4096, 32768, 65536, 262144]
 PATH = {0: "k_sweep direct", 1: "k_sweep memoised", 2: "k_sweep_bin", 3: "k_sweep_par4/wide", 5: "k_sweep_strict", 6: "k_sweep_pw4", 8: "k_sweep_dir4",
-        9: "k_sweep_chroma", 16: "k_sweep direct, state in global memory", 17: "k_sweep memoised, state in global memory"}
+        9: "k_sweep_chroma", 11: "k_sweep_bits (bit-packed state)", 16: "k_sweep direct, state in global memory", 17: "k_sweep memoised, state in global memory"}
 
 
 def rows():
