@@ -744,7 +744,7 @@ void gr_sampler::rebuild() {
         // Chosen by the sampler itself (fast_form 0) where the STATE is what fills LDS: a model whose byte layout leaves a CU one block
         // and whose bit layout leaves it two (dv-rel_2: 1 200 variables, 144 KB -> 58 KB, 1.4e11 -> 4.8e11 updates/s); everywhere
         // else the form costs 13 more VALU instructions per 64 updates than the byte layout and is slower (profiles/r03_bits_form.txt).
-        const bool bits_can = par && !par_tabg && fast_slots <= 12 && (uint64_t)n_vars * 8u < 65536u && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SCAN_SYSTEMATIC));
+        const bool bits_can = par && (!par_tabg || par_tab_words == 0) && fast_slots <= 12 && (uint64_t)n_vars * 8u < 65536u && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SCAN_SYSTEMATIC));
         uint32_t bits_need = 0;
         if (bits_can) {
             uint32_t nfree_max = 1, cpt_max = 4;
@@ -753,7 +753,7 @@ void gr_sampler::rebuild() {
                 cpt_max = std::max<uint32_t>(cpt_max, (image[g].cpt_words + 3u) & ~3u);
             }
             const uint32_t hist_off = ((uint32_t)n_vars * 8u + 15u) & ~15u, tab_off = (hist_off + nfree_max * 8u + 15u) & ~15u;
-            bits_need = (tab_off + cpt_max * 4u + 15u) & ~15u;
+            bits_need = par_tabg ? tab_off : (tab_off + cpt_max * 4u + 15u) & ~15u; // (a pool too large for LDS stays in global memory)
         }
         // (state-dominated: the chains' bytes alone take more than half of a CU's LDS; models whose TABLES fill LDS keep the byte layout and its wide forms)
         const bool bits_auto = o.fast_form == 0 && bits_can && !strict_fast && (uint64_t)n_vars * kParStateStride > kLdsBudget / 2u && par_lds > kLdsBudget / 2u && bits_need <= kLdsBudget / 2u;
@@ -773,7 +773,7 @@ void gr_sampler::rebuild() {
                     uint32_t r[16] = {0};
                     // absolute LDS addresses of the kernel's layout: masks | histogram pairs (by rank) | tables
                     const uint32_t hist_g = ((uint32_t)n_vars * 8u + 15u) & ~15u, tab_g = (hist_g + (uint32_t)im.free_vars.size() * 8u + 15u) & ~15u;
-                    r[0] = v * 8u; r[1] = hist_g + 8u * rank; r[2] = tab_g + cp[2] * 4u; r[3] = nn;
+                    r[0] = v * 8u; r[1] = hist_g + 8u * rank; r[2] = (par_tabg ? 0u : tab_g) + cp[2] * 4u; r[3] = nn;
                     for (uint32_t i = 0; i < 12u; ++i) r[4 + i] = ((i < nn ? cp[3 + 2 * i] : v) * 8u) | ((i < nn ? cp[4 + 2 * i] * 4u : 0u) << 16);
                     rb.insert(rb.end(), r, r + 16);
                     ++rank;
@@ -782,7 +782,7 @@ void gr_sampler::rebuild() {
             rb.resize(rb.size() + 16, 0);
             d_recs_bits.upload(rb, stream, stage);
             const uint32_t hist_off = ((uint32_t)n_vars * 8u + 15u) & ~15u, tab_off = (hist_off + nfree_max * 8u + 15u) & ~15u;
-            bits_lds = (tab_off + cpt_max * 4u + 15u) & ~15u;
+            bits_lds = par_tabg ? std::max(tab_off, 64u) : (tab_off + cpt_max * 4u + 15u) & ~15u;
             if (bits_lds > kLdsBudget) throw Error(GR_E_UNSUPPORTED, "fast_form 11 (bit-packed state): the tables do not fit LDS");
         }
 

@@ -39,7 +39,8 @@ __device__ __forceinline__ uint32_t mad_u16_hi_b(const uint32_t w, const uint32_
 }
 } // namespace
 
-template <int SLOTS, bool COUNT>
+// TABG: the threshold pool stays in global memory (pools too large for LDS: record word 2 = byte offset into the group's pool)
+template <int SLOTS, bool COUNT, bool TABG = false>
 __global__ void __launch_bounds__(256) k_sweep_bits(const FastParams p) {
     extern __shared__ __align__(16) unsigned char lds[];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, j = lane >> 4, c = lane & 15u;
@@ -52,7 +53,8 @@ __global__ void __launch_bounds__(256) k_sweep_bits(const FastParams p) {
     {
         const uint4 *src = reinterpret_cast<const uint4 *>(p.cpt + vd.cpt_base);
         uint4 *dst = reinterpret_cast<uint4 *>(lds + tab_off);
-        for (uint32_t i = tid; i < ((vd.cpt_len + 3u) >> 2); i += 256u) dst[i] = src[i];
+        if constexpr (!TABG)
+            for (uint32_t i = tid; i < ((vd.cpt_len + 3u) >> 2); i += 256u) dst[i] = src[i];
         uint32_t *h = reinterpret_cast<uint32_t *>(lds + hist_off);
         for (uint32_t i = tid; i < 2u * vd.n_free; i += 256u) h[i] = 0;
         // pack: step slot j takes the variables v = j (mod 4); the compare's lane mask holds one variable per DPP row
@@ -76,6 +78,7 @@ __global__ void __launch_bounds__(256) k_sweep_bits(const FastParams p) {
     const uint32_t nq = p.n_steps >> 2; // multiple of 4
     const uint32_t *gplan = p.plan + (size_t)group * p.plan_pitch + j;
     const unsigned char *recs_g = reinterpret_cast<const unsigned char *>(p.recs_par);
+    const unsigned char *tabg = reinterpret_cast<const unsigned char *>(p.cpt + vd.cpt_base);
     const bool tail = c == 15u, hi_half = j >= 2u;
     const uint32_t sl_shift = 16u * (j & 1u); // my step slot's 16 bits inside its half of a lane mask
 
@@ -89,7 +92,8 @@ __global__ void __launch_bounds__(256) k_sweep_bits(const FastParams p) {
         uint32_t a = h.z; // table address
 #pragma unroll
         for (int i = SLOTS - 1; i >= 0; --i) a = mad_u16_hi_b(sw[i / 4][i % 4], __builtin_amdgcn_ubfe(m[i], c, 1u), a); // bit (chain) of the mask x multiplier
-        return u >= *(lds_u32b_t *)(uintptr_t)a;
+        if constexpr (TABG) return u >= *reinterpret_cast<const uint32_t *>(tabg + a);
+        else return u >= *(lds_u32b_t *)(uintptr_t)a;
     };
 
     const PrioRotor prio;
@@ -196,6 +200,7 @@ static hipError_t launch_bits_t(const FastParams &p, uint32_t blocks, uint32_t l
         hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, p);
         return hipGetLastError();
     };
+    if (p.tab_global) return p.counting ? go(&k_sweep_bits<SLOTS, true, true>) : go(&k_sweep_bits<SLOTS, false, true>);
     return p.counting ? go(&k_sweep_bits<SLOTS, true>) : go(&k_sweep_bits<SLOTS, false>);
 }
 
