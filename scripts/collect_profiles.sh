@@ -38,4 +38,10 @@ for spec in "ObjectDetection_13.uai 256 50 400" "Segmentation_11.uai 256 20 100"
   python3 $R/scripts/dev_noise.py $spec 2>&1 | tail -8 >> $O/seed_noise.txt
 done
 python3 $R/scripts/dev_advance_chain.py > $O/advance_chain.txt 2>&1
+python3 $R/scripts/dev_chains.py > $O/dev_chains.txt 2>&1
+python3 $R/scripts/dev_bits.py > $O/dev_bits.txt 2>&1
+python3 $R/scripts/dev_exp_rounds.py 0 > $O/adaptive_rounds.txt 2>&1
+python3 $R/scripts/dev_prio.py > $O/dev_prio.txt 2>&1
+GR_DEV_PRIO_SHIFT=32 python3 $R/scripts/dev_prio.py >> $O/dev_prio.txt 2>&1
+$R/scripts/ubench/state_form.bin > $O/state_form_ubench_run.txt 2>&1
 echo "all done"

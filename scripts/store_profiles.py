@@ -26,7 +26,8 @@ def main():
     for src, dst in (("bench.json", "bench.json"), ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("configs.jsonl", "configs.jsonl"),
                      ("stats/run_kernel_stats.csv", "kernel_stats.csv"), ("dev_time.txt", "dev_time.txt"), ("dev_od.txt", "dev_od.txt"), ("dev_wide.txt", "dev_wide.txt"), ("dev_systematic.txt", "dev_systematic.txt"), ("issue_rate_ubench.txt", "issue_rate_ubench.txt"),
                      ("all_models_32768.txt", "all_models_32768.txt"), ("parity_configs.jsonl", "parity_configs.jsonl"),
-                     ("seed_noise.txt", "seed_noise.txt"), ("advance_chain.txt", "advance_chain.txt")):
+                     ("seed_noise.txt", "seed_noise.txt"), ("advance_chain.txt", "advance_chain.txt"), ("dev_chains.txt", "dev_chains_run.txt"), ("dev_bits.txt", "dev_bits_run.txt"),
+                     ("adaptive_rounds.txt", "adaptive_rounds_run.txt"), ("dev_prio.txt", "dev_prio.txt"), ("state_form_ubench_run.txt", "state_form_ubench_run.txt")):
         if os.path.exists(os.path.join(G, src)):
             shutil.copy(os.path.join(G, src), os.path.join(P, f"{TAG}_{dst}"))
     for tag in ("fetch", "write", "sqA", "sqB", "gui"):
