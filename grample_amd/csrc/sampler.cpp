@@ -223,6 +223,7 @@ struct gr_sampler {
     // the 8-lane form on the sweep order is the faster one (Segmentation_11 collapsed, 32 768 chains: 3.9e11 against 1.6e11)
     bool use_chroma(uint32_t act) const { return sysscan && chroma && (chroma_rec_off == 0 || act <= 8192u || !sys_wide_ok()); }
     bool sys_wide() const { return sys_wide_ok() && !use_chroma(active_chains()); }
+    bool sys_bits() const { return sysscan && bits && fast && par && !strict_fast && !use_chroma(active_chains()) && !sys_wide(); }
     bool dir4_chain = false;          // ... with chained factor entries (a factor of arity > 4 or with strides past 16 bits: collapse factors)
     // factor entries of variable v's list in the form this sampler uses: one per factor, or one per pair of other scope variables
     uint32_t dir4_entries(const VariantImage &im, uint32_t v) const {
@@ -744,7 +745,7 @@ void gr_sampler::rebuild() {
         // Chosen by the sampler itself (fast_form 0) where the STATE is what fills LDS: a model whose byte layout leaves a CU one block
         // and whose bit layout leaves it two (dv-rel_2: 1 200 variables, 144 KB -> 58 KB, 1.4e11 -> 4.8e11 updates/s); everywhere
         // else the form costs 13 more VALU instructions per 64 updates than the byte layout and is slower (profiles/r03_bits_form.txt).
-        const bool bits_can = par && (!par_tabg || par_tab_words == 0) && fast_slots <= 12 && (uint64_t)n_vars * 8u < 65536u && !(o.flags & (GR_FLAG_SCAN_PER_CHAIN | GR_FLAG_SCAN_SYSTEMATIC));
+        const bool bits_can = par && (!par_tabg || par_tab_words == 0) && fast_slots <= 12 && (uint64_t)n_vars * 8u < 65536u && !(o.flags & GR_FLAG_SCAN_PER_CHAIN);
         uint32_t bits_need = 0;
         if (bits_can) {
             uint32_t nfree_max = 1, cpt_max = 4;
@@ -1079,8 +1080,8 @@ void gr_sampler::run(uint64_t updates, bool counting) {
             else lpc = auto_lpc(act / 64u);
             if (sys && lpc == 4) lpc = 8; // (the systematic scan exists in the wide forms only: k_sweep_par4 is left as it is)
         }
-        if (sys && lpc == 4) throw Error(GR_E_STATE, "systematic scan on the 4-lane form (internal error)");
-        const bool use_bits = bits && par && lpc == 4 && !cur_log && !cur_limit && !sys; // (logged windows keep the byte layout's kernels)
+        const bool use_bits = bits && par && lpc == 4 && !cur_log && !cur_limit; // (logged windows keep the byte layout's kernels)
+        if (sys && lpc == 4 && !use_bits) throw Error(GR_E_STATE, "systematic scan on the 4-lane form (internal error)");
         if (use_bits) { f.rec_stride = 64; f.recs_par = d_recs_bits.p; }
         if (par) lpc_last = lpc;
         uint32_t first_n = 0;             // plan-ahead: this call's first launch
@@ -1230,6 +1231,7 @@ void gr_sampler::run(uint64_t updates, bool counting) {
         else if (pw4) { p.sys_order = d_sys_order.p; generic(left); left = 0; } // k_scan_vars + k_sweep_pw4<SYS>
         else if (dir4 && !fast) { run_dir4(left, true); left = 0; }
         else if (sys_wide()) { run_fast(left, true); left = 0; } // memoised binary models the chromatic kernel does not take: k_sweep_wide
+        else if (sys_bits()) { run_fast(left, true); left = 0; } // ... or, where the wide form's LDS layout does not fit (state-dominated models), k_sweep_bits
         if (left) sys_generic(left);
     } else if (dir4 && !fast) {
         run_dir4(updates, false);
@@ -2367,7 +2369,7 @@ GR_VISIBLE int gr_sampler_get_info(gr_sampler *s, gr_sampler_info *out) {
         out->block_threads = s->T; out->n_blocks = s->blocks;
         out->lds_bytes = s->use_chroma(s->active_chains()) ? s->chroma_lds : s->bits ? s->bits_lds : s->fast && s->par ? s->par_lds : s->pw4 ? s->pw4_lds : s->dir4 ? s->dir_lds : s->lds; // of the kernel that actually runs
         if (s->fast && s->par) { out->block_threads = s->strict_fast ? s->T : 64u * s->lpc_last; out->n_blocks = s->active_chains() / 64u; } // (64 x lanes per chain of the last launch)
-        out->path = s->sysscan ? (s->use_chroma(s->active_chains()) ? 9u : s->pw4 ? 6u : (s->dir4 && !s->fast) ? 8u : s->sys_wide() ? 3u : 0u) : s->fast ? (s->strict_fast ? 5u : s->bits ? 11u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
+        out->path = s->sysscan ? (s->use_chroma(s->active_chains()) ? 9u : s->pw4 ? 6u : (s->dir4 && !s->fast) ? 8u : s->sys_wide() ? 3u : s->sys_bits() ? 11u : 0u) : s->fast ? (s->strict_fast ? 5u : s->bits ? 11u : s->par ? 3u : 2u) : (s->pw4 ? 6u : s->dir4 ? 8u : s->cpt ? 1u : 0u) + (s->stg ? 16u : 0u); out->max_card = (uint32_t)s->max_card; out->tables_in_lds = s->tab_lds ? 1u : (s->par && s->par_tabg && s->par_tab_words) ? 2u : 0u;
         out->n_launches_last = s->launches_last; out->kernel_ms_last = s->kernel_ms_last; out->step = s->step;
     });
 }

@@ -96,6 +96,15 @@ __global__ void __launch_bounds__(256) k_sweep_bits(const FastParams p) {
         else return u >= *(lds_u32b_t *)(uintptr_t)a;
     };
 
+    // GR_FLAG_SCAN_SYSTEMATIC (p.sys_rank set): the plan follows the sweep order; my steps are 4 apart
+    const bool sys = p.sys_rank != nullptr;
+    uint64_t sys_sweep = 0;
+    uint32_t sys_pos = 0;
+    if (sys) {
+        const uint64_t s_first = (q0 << 2) + j;
+        sys_sweep = s_first / vd.n_free;
+        sys_pos = (uint32_t)(s_first - sys_sweep * vd.n_free);
+    }
     const PrioRotor prio;
     // plan words two iterations ahead, records one iteration ahead (global memory: the vector-memory path is otherwise idle)
     uint32_t pwa[4], pwn[4];
@@ -125,11 +134,20 @@ __global__ void __launch_bounds__(256) k_sweep_bits(const FastParams p) {
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) fetch(k);
-        // draws: my Philox call is quad g0 + j; the 4 x 4 transpose of k_sweep_par4
-        const uint64_t q = q0 + g0 + j;
-        const u32x4 W = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
         uint32_t U[4];
-        {
+        if (sys) { // GR_FLAG_SCAN_SYSTEMATIC: one Philox call per step, keyed by (sweep, position) -- see k_sweep_dir4
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const u32x4 d = philox_sys_draw(sys_sweep, sys_pos, gchain, p.seed_lo, p.seed_hi);
+                const uint32_t w = (uint32_t)sys_sweep & 3u;
+                U[k] = w == 0 ? d.x : w == 1 ? d.y : w == 2 ? d.z : d.w;
+                sys_pos += 4u;
+                while (sys_pos >= vd.n_free) { sys_pos -= vd.n_free; ++sys_sweep; }
+            }
+        } else {
+            // draws: my Philox call is quad g0 + j; the 4 x 4 transpose of k_sweep_par4
+            const uint64_t q = q0 + g0 + j;
+            const u32x4 W = philox4x32_10((uint32_t)q, (uint32_t)(q >> 32), (uint32_t)gchain, DOM_DRAW + ((uint32_t)(gchain >> 32) << 4), p.seed_lo, p.seed_hi);
             const auto a = __builtin_amdgcn_permlane32_swap(W.x, W.z, false, false);
             const auto b = __builtin_amdgcn_permlane32_swap(W.y, W.w, false, false);
             const auto cc = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);

@@ -140,7 +140,7 @@ def test_systematic_marginals_match_oracle_random_scan(oracle, res_dir, name, bu
 @pytest.mark.parametrize("name,ev,chains,path", [("ObjectDetection_13.uai", False, 2048, 6), ("ObjectDetection_11.uai", False, 1024, 6), ("CSP_13.uai", False, 2048, 8),
                                                   ("Alchemy_11.uai", False, 1024, 8), ("Pedigree_11.uai", False, 1024, 8),
                                                   ("Promedus_14.uai", False, 1024, 3), ("Promedus_14.uai", False, 40960, 3), ("Promedus_11.uai", True, 2048, 3),
-                                                  ("Promedus_17.uai", True, 512, 3)])
+                                                  ("Promedus_17.uai", True, 512, 3), ("dv-rel_2.uai", False, 1024, 11), ("dv-rel_2.uai", True, 512, 11)])  # (11: k_sweep_bits, the state-dominated model)
 def test_plan_based_kernels_equal_generic_systematic(res_dir, name, ev, chains, path):
     """The systematic scan on the plan-based kernels (k_sweep_pw4: path 6, k_sweep_dir4: path 8, k_sweep_wide with 8 or 16 lanes
     per chain: path 3 -- the plan follows the sweep order, draws are keyed by (sweep, position)) is the generic kernel's
@@ -148,7 +148,7 @@ def test_plan_based_kernels_equal_generic_systematic(res_dir, name, ev, chains, 
     m = g.Model.NewModelFromFile(os.path.join(res_dir, name), ev)
     n = m.n_vars
     out = []
-    for flags in (SYS, SYS | (g.GR_FLAG_DIRECT if path == 3 else g.GR_FLAG_CHAIN_PER_LANE)):
+    for flags in (SYS, SYS | (g.GR_FLAG_DIRECT if path in (3, 11) else g.GR_FLAG_CHAIN_PER_LANE)):
         s = g.HIPChains(m, chains, seed=9, chain_offset=(1 << 35) + 64 * 3, flags=flags)
         s.BurnIn(45); s.Advance(3 * n + 7); s.Advance(66); s.Advance(2 * n)
         out.append((s.info()["path"], s.counts(), s.checkpoint()["states"]))
