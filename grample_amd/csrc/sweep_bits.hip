@@ -5,6 +5,10 @@
 // a variable for the 16 chains of a wavefront is ONE 16-bit mask in LDS (8 bytes per variable and block instead of 80): a step
 // slot reads its neighbours' masks with row-uniform ds_read_u16, extracts bit (chain) of each, and writes the variable's new mask
 // as the 16-bit slice of the compare's lane mask.  Bit-identical to every other form.
+// Reference path, per update: VarSample sampler/sampler.go:135-174 (the scan plan), the gather of the blanket's state
+// gibbs-simple.go:186-220 (here: bit (chain) of each neighbour's mask -> configuration index), stabilise / exp / floor :227-258 and
+// WeightedSample sampler.go:90-130 (the memoised threshold of that configuration against the chain's draw), write-back :262-270
+// (the mask slice), Marginal[val] += 1 chain.go:230-236 (the (zeros, ones) histogram pair).
 //
 // Built to MEASURE the form, not to replace the byte layout: the inner loop needs the same number of LDS instructions (a
 // row-uniform u16 read costs the LDS pipe what a per-lane byte read does) and ~10 VALU instructions more per step for the bit

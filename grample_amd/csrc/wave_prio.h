@@ -1,4 +1,5 @@
-// Rotating wavefront priority for the sweep kernels (device code only).
+// Rotating wavefront priority for the sweep kernels (device code only).  (No counterpart in the reference: its chains are goroutines the Go
+// scheduler runs, sampler/chain.go:197-215; here they are wavefronts a SIMD's arbiter picks from.)
 //
 // A gfx950 SIMD's arbiter serves its OLDEST wavefront first.  The sweep kernels are long loops of equal work per block, and a
 // CU holds a few blocks at once (one wavefront of each per SIMD): the block that arrived first runs ahead of the others all
